@@ -1,0 +1,232 @@
+/*
+ * quorum_hip.h -- C ABI of libquorum_hip: Quorum's quality-aware k-mer database
+ * build and database_query lookups on AMD MI355X (gfx950).
+ *
+ * Plain C: opaque handles, pointers and sizes, int status returns, no C++ or
+ * torch types.  Every entry point names the upstream Quorum interface it
+ * replaces (paths relative to the Quorum source tree).  Upstream reports errors
+ * with C++ exceptions / exit(1); here every call returns a qh_status and the
+ * message is available from qh_last_error() (thread-local).
+ *
+ * Value encoding everywhere: v = count << 1 | hq   (src/mer_database.hpp:102-111),
+ * 0 = k-mer absent (database_query::operator[] returns (0,0), :284-293).
+ * K-mer encoding: jellyfish::mer_dna, A=0 C=1 G=2 T=3, base 0 (the LAST
+ * character of the string) in the two low bits, k <= 31.
+ *
+ * Threading: a build handle is driven by one host thread at a time (the GPU
+ * supplies the parallelism that upstream gets from -t threads).  A query handle
+ * is immutable after open; concurrent calls on one handle serialise on an
+ * internal mutex (each call owns the handle's staging buffers).
+ */
+#ifndef QUORUM_HIP_H
+#define QUORUM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum qh_status {
+  QH_OK = 0,
+  QH_EBADARG = 1,  /* invalid argument / unsupported geometry                       */
+  QH_EFULL = 2,    /* "Hash is full" (create_database.cc:86-87): cannot grow         */
+  QH_EIO = 3,      /* file open/read/write failure                                   */
+  QH_EHIP = 4,     /* a HIP runtime call failed                                      */
+  QH_EFORMAT = 5,  /* FASTQ chunk is not in strict 4-line form / invalid FASTQ       */
+  QH_ENOMEM = 6
+} qh_status;
+
+typedef struct qh_build qh_build; /* ~ hash_with_quality + quality_mer_counter */
+typedef struct qh_query qh_query; /* ~ database_query                          */
+
+/* One parsed FASTQ record inside a chunk: sequence bytes [seq_off, seq_off+len)
+ * and quality bytes [qual_off, qual_off+len) of the same buffer. */
+typedef struct qh_record {
+  uint32_t seq_off;
+  uint32_t len;
+  uint32_t qual_off;
+  uint32_t reserved;
+} qh_record;
+
+typedef struct qh_build_stats {
+  uint64_t instances;     /* counted_low  of create_database.cc:58,89  */
+  uint64_t hq_instances;  /* counted_high of create_database.cc:58,88  */
+  uint64_t distinct;      /* occupied slots                            */
+  uint64_t slots;         /* table size of this shard (power of two)   */
+  uint64_t records;       /* reads consumed                            */
+  uint64_t grows;         /* number of 2x table doublings performed    */
+  uint64_t foreign;       /* k-mers dropped because another shard owns them */
+} qh_build_stats;
+
+const char* qh_last_error(void);
+const char* qh_version(void);
+
+/* ------------------------------------------------------------------ build side */
+
+/* hash_with_quality::hash_with_quality(size, key_len=2k, bits, nb_threads, reprobe_limit)
+ * (src/mer_database.hpp:78-87) together with the argument rules of
+ * create_database main (src/create_database.cc:105-112): k in 1..31, bits in 1..63
+ * (and small enough that remainder+probe+value fit one 64-bit slot), size is
+ * rounded up to a power of two like large_hash::array does, min_qual is the
+ * threshold compared as a signed char (:48,:81,:110).  device = HIP device id.
+ * shard_bits/shard_id: this handle owns shard `shard_id` of 2^shard_bits
+ * hash-partitioned shards (0,0 = unsharded). */
+int qh_build_create(qh_build** out, int k, int bits, uint64_t size, int min_qual,
+                    int reprobe_limit, int device, int shard_bits, int shard_id);
+void qh_build_destroy(qh_build* h);
+
+/* Use an existing HIP stream (hipStream_t passed as void*) for all work of this
+ * handle; NULL = the handle's own stream.  No upstream counterpart. */
+int qh_build_set_stream(qh_build* h, void* hip_stream);
+
+/* quality_mer_counter::start over one chunk of FASTQ text
+ * (src/create_database.cc:56-95; the chunk plays the role of the parser jobs of
+ * :52,:61-66).  The chunk must begin at a record start and end at a record end.
+ * _device: `buf` is device memory already resident in HBM; the call only
+ * enqueues kernels.  The host variant copies the chunk to the device first.
+ * The GPU fast path accepts strict 4-line records; anything else is detected
+ * on the device, nothing of the chunk is inserted, and qh_build_sync() reports
+ * QH_EFORMAT so the caller can re-submit through qh_build_add_fastq_host_parsed. */
+int qh_build_add_fastq_device(qh_build* h, const void* dev_buf, size_t len);
+int qh_build_add_fastq(qh_build* h, const char* buf, size_t len);
+
+/* Same chunk semantics, but records are found by the sequential host parser
+ * that follows jellyfish::whole_sequence_parser's FASTQ rules (multi-line
+ * sequence/quality accepted; "Truncated fastq file", "wrong number of quals",
+ * "header missing" become QH_EFORMAT).  *consumed receives the number of bytes
+ * that formed complete records when `final_chunk` is 0 (a trailing partial
+ * record is left for the next call); with final_chunk != 0 the whole buffer
+ * must parse. */
+int qh_build_add_fastq_host_parsed(qh_build* h, const char* buf, size_t len,
+                                   int final_chunk, size_t* consumed);
+
+/* Pre-indexed records over a device-resident buffer (record table in host memory). */
+int qh_build_add_records_device(qh_build* h, const void* dev_buf, size_t len,
+                                const qh_record* recs, size_t nrec);
+
+/* hash_with_quality::add(mer, quality) batched (src/mer_database.hpp:94-113).
+ * mers are inserted as given (upstream add() does not canonicalise either).
+ * _device takes packed items  mer << 1 | quality  in device memory. */
+int qh_build_add_mers(qh_build* h, const uint64_t* mers, const uint8_t* quality, size_t n);
+int qh_build_add_mers_device(qh_build* h, const uint64_t* dev_items, size_t n);
+
+/* Waits for queued work, performs table doubling when a chunk overflowed
+ * (the role of handle_full_ary, src/mer_database.hpp:137-187) and returns the
+ * first deferred error: QH_EFULL (growth impossible), QH_EFORMAT, QH_EHIP. */
+int qh_build_sync(qh_build* h);
+
+/* hash_with_quality::done (src/mer_database.hpp:128-131): end of input. */
+int qh_build_finish(qh_build* h, qh_build_stats* stats);
+int qh_build_get_stats(qh_build* h, qh_build_stats* stats);
+
+/* Empty the table and counters (used between benchmark steps). */
+int qh_build_reset(qh_build* h);
+
+/* hash_with_quality::write(os, &header) (src/mer_database.hpp:115-126) with
+ * header.fill_standard()/set_cmdline (src/create_database.cc:100-102). */
+int qh_build_write(qh_build* h, const char* path, int argc, const char* const* argv);
+
+/* Sharded serialisation: every shard pwrite()s its slice of the keys and vals
+ * images into one file. The shard called with write_header != 0 must run first
+ * (it creates the file and sizes it); all shards must have the same table size
+ * (see qh_build_grow_to). No upstream counterpart (upstream is one process). */
+int qh_build_write_shard(qh_build* h, const char* path, int argc, const char* const* argv,
+                         int write_header);
+
+/* Doubles this shard's table until it has at least 2^lsize slots (used to
+ * equalise shard sizes before qh_build_write_shard). */
+int qh_build_grow_to(qh_build* h, int lsize);
+
+/* Number of leading bytes of a FASTQ buffer that form whole groups of 4 lines:
+ * where the CLI cuts a stream into chunks for the GPU fast path. */
+size_t qh_fastq_4line_prefix(const char* buf, size_t len, int final_chunk);
+
+/* Content export: every (mer, value) of this shard, unordered.  *n receives the
+ * number of entries; at most cap are written (call with cap=0 to size). */
+int qh_build_dump(qh_build* h, uint64_t* mers, uint64_t* vals, uint64_t cap, uint64_t* n);
+
+/* A query handle over the live table (no file round trip).  The build handle
+ * must outlive it and must not be modified while it is in use. */
+int qh_build_as_query(qh_build* h, qh_query** out);
+
+/* Multi-GPU exchange support (no upstream counterpart).  Extracts the
+ * chunk's (canonical mer, hq) items, packed mer << 1 | hq, bucketed by owner
+ * shard: items for shard s are written to dev_out[s*cap_per_shard ...] and their
+ * number to dev_counts[s] (uint64, device memory, zeroed by the call). */
+int qh_build_extract_partitioned_device(qh_build* h, const void* dev_buf, size_t len,
+                                        uint64_t* dev_out, uint64_t cap_per_shard,
+                                        uint64_t* dev_counts);
+
+/* -------------------------------------------------------------- query side */
+
+/* database_header fields (src/mer_database.hpp:43-63 + jellyfish::file_header) of
+ * a database file, read without touching a GPU. QH_EFORMAT when the format string
+ * is not "binary/quorum_db" (check_format, :60-62). */
+typedef struct qh_db_info {
+  uint64_t size;         /* slots                         header.size()        */
+  uint64_t key_bytes;    /*                               header.key_bytes()   */
+  uint64_t value_bytes;  /*                               header.value_bytes() */
+  uint64_t offset;       /* start of the keys image       header.offset()      */
+  uint32_t key_len;      /* 2k                            header.key_len()     */
+  uint32_t val_len;      /* 0                             header.val_len()     */
+  uint32_t max_reprobe;  /*                               header.max_reprobe() */
+  uint32_t bits;         /* count bits                    header.bits()        */
+  uint32_t shard_bits;
+  uint32_t window_bits;
+  char format[32];
+} qh_db_info;
+int qh_db_header_info(const char* path, qh_db_info* info);
+
+/* database_query::database_query(filename, no_mmap) (src/mer_database.hpp:270-278):
+ * parses the header and loads the table into HBM of `device`. */
+int qh_query_open(qh_query** out, const char* path, int device);
+void qh_query_close(qh_query* q);
+
+/* header().key_len()/2, header().bits(), header().size() (src/mer_database.hpp:280,
+ * src/error_correct_reads.cc:690, unit_tests/test_mer_database.cc:113-114). */
+int qh_query_info(const qh_query* q, int* k, int* bits, uint64_t* size);
+
+/* database_query::operator[] batched (src/mer_database.hpp:284-293). The caller
+ * passes canonical mers, as upstream callers do. out[i] = count<<1|hq, 0 absent. */
+int qh_query_batch(qh_query* q, const uint64_t* mers, size_t n, uint64_t* out);
+int qh_query_batch_device(qh_query* q, const uint64_t* dev_mers, size_t n, uint64_t* dev_out,
+                          void* hip_stream);
+
+/* database_query::get_val batched (src/mer_database.hpp:296-299): hq ? count : 0 */
+int qh_query_get_val_batch(qh_query* q, const uint64_t* mers, size_t n, uint64_t* out);
+
+/* database_query::get_best_alternatives batched (src/mer_database.hpp:302-329).
+ * fmers[i] is the forward mer of a kmer_t; backward[i] = 0 for forward_mer
+ * (varies base 0), 1 for backward_mer (varies base k-1, src/kmer.hpp:96-103).
+ * counts is [n][4]; ucode/level/nkept are [n] (ucode = 0 when nothing kept,
+ * matching the caller-side initialisation at src/error_correct_reads.cc:410). */
+int qh_query_best_alternatives_batch(qh_query* q, const uint64_t* fmers, const uint8_t* backward,
+                                     size_t n, uint64_t* counts, int32_t* ucode, int32_t* level,
+                                     int32_t* nkept);
+
+/* compute_poisson_cutoff__'s table reduction (src/error_correct_reads.cc:650-659):
+ * distinct = #{v : (v&1) && v>=2}, total = sum of their counts. */
+int qh_query_stats(qh_query* q, uint64_t* distinct, uint64_t* total);
+
+/* histo_mer_database (src/histo_mer_database.cc:13-21): histo[min(count,1000)][hq] */
+int qh_query_histo(qh_query* q, uint64_t* histo /* [1001][2] */);
+
+/* database_query::begin()/end() iteration (src/mer_database.hpp:331-361) as a
+ * bulk export of (mer, value) pairs. */
+int qh_query_dump(qh_query* q, uint64_t* mers, uint64_t* vals, uint64_t cap, uint64_t* n);
+
+/* -------------------------------------------------- measurement support */
+
+/* Random-access roofline microbenchmark: n_updates uniformly random
+ * 64-bit atomicCAS (mode 0) or 8-byte loads (mode 1) over a table of 2^lsize
+ * words on `device`; returns the average kernel time of `iters` launches in
+ * milliseconds through *ms. */
+int qh_bench_random_access(int device, int lsize, uint64_t n_updates, int mode, int iters,
+                           double* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUORUM_HIP_H */

@@ -1,0 +1,634 @@
+// qh_build.hip -- build side of the C ABI (include/quorum_hip.h): the host logic
+// around the gfx950 kernels that replaces hash_with_quality + quality_mer_counter
+// (src/mer_database.hpp:65-188, src/create_database.cc:44-96).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <unistd.h>
+#include <fcntl.h>
+#include <errno.h>
+#include <string>
+#include <vector>
+
+#include "qh_host.h"
+#include "qh_kernels.h"
+#include "qh_dbfile.h"
+#include "qh_internal.h"
+
+// ------------------------------------------------------------------- errors
+
+static thread_local std::string g_last_error;
+
+void qh_set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+
+int qh_fail(int status, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return status;
+}
+
+extern "C" const char* qh_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char* qh_version(void) { return "quorum_hip 0.1 (gfx950)"; }
+
+// ----------------------------------------------------------------- geometry
+
+static int bitsize(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
+
+bool qh_make_geom(int k, int bits, uint64_t size, int min_qual, int reprobe_limit, int shard_bits,
+                  int shard_id, int wbits_override, qh_geom& g, std::string& err) {
+  char m[256];
+  if (k < 1 || k > 31) { snprintf(m, sizeof m, "Mer length must be between 1 and 31 (got %d)", k); err = m; return false; }
+  if (bits < 1 || bits > 63) { err = "The number of bits should be between 1 and 63"; return false; }  // create_database.cc:111-112
+  if (size == 0) { err = "Initial hash size must be positive"; return false; }
+  if (shard_bits < 0 || shard_bits > 8 || shard_id < 0 || shard_id >= (1 << shard_bits)) { err = "invalid shard specification"; return false; }
+  if (reprobe_limit < 0) reprobe_limit = 0;
+  int lsize = 0;
+  while (lsize < 48 && (1ull << lsize) < size) ++lsize;  // large_hash::array: size -> 2^ceilLog2(size)
+  if ((1ull << lsize) < size) { err = "hash size too large"; return false; }
+  if (lsize < 4) lsize = 4;
+  memset(&g, 0, sizeof g);
+  g.k = k; g.bits = bits; g.vbits = bits + 1;
+  g.lsize = lsize; g.shard_bits = shard_bits; g.shard_id = shard_id;
+  g.wbits = wbits_override >= 0 ? wbits_override : (lsize < QH_WINDOW_BITS ? lsize : QH_WINDOW_BITS);
+  if (g.wbits > lsize) g.wbits = lsize;
+  uint64_t maxr = (1ull << g.wbits) - 1;
+  g.max_reprobe = (int)((uint64_t)reprobe_limit < maxr ? (uint64_t)reprobe_limit : maxr);
+  g.pbits = bitsize((uint64_t)g.max_reprobe + 1);
+  const int gsize = lsize + shard_bits;
+  g.rbits = 2 * k > gsize ? 2 * k - gsize : 0;
+  g.min_qual = min_qual;
+  g.kmask = qh_low_mask(2 * k);
+  g.vmask = qh_low_mask(g.vbits);
+  g.max_val = ~0ull >> (64 - bits);  // mer_database.hpp:83
+  if (g.vbits + g.pbits + g.rbits > 64) {
+    snprintf(m, sizeof m,
+             "unsupported geometry: %d remainder + %d probe + %d value bits exceed one 64-bit slot "
+             "(use a larger -s, a smaller -b or a smaller -p)", g.rbits, g.pbits, g.vbits);
+    err = m;
+    return false;
+  }
+  return true;
+}
+
+// --------------------------------------------------------------- the handle
+
+static int ensure(void** p, size_t* cap, size_t need, const char* what) {
+  if (*cap >= need && *p) return QH_OK;
+  if (*p) { hipError_t e = hipFree(*p); (void)e; *p = nullptr; *cap = 0; }
+  size_t want = need + need / 8 + 256;
+  hipError_t e = hipMalloc(p, want);
+  if (e != hipSuccess) { *p = nullptr; return qh_fail(QH_ENOMEM, "hipMalloc of %zu bytes for %s failed: %s", want, what, hipGetErrorString(e)); }
+  *cap = want;
+  return QH_OK;
+}
+
+extern "C" int qh_build_create(qh_build** out, int k, int bits, uint64_t size, int min_qual, int reprobe_limit,
+                               int device, int shard_bits, int shard_id) {
+  if (!out) return qh_fail(QH_EBADARG, "null output handle");
+  *out = nullptr;
+  qh_geom g;
+  std::string err;
+  // sharded: `size` is the TOTAL table size; every shard gets size / 2^shard_bits
+  uint64_t local = size >> shard_bits;
+  if (shard_bits && (local << shard_bits) < size) ++local;
+  if (!qh_make_geom(k, bits, local ? local : 1, min_qual, reprobe_limit, shard_bits, shard_id, -1, g, err))
+    return qh_fail(QH_EBADARG, "%s", err.c_str());
+  QH_HIP(hipSetDevice(device));
+  qh_build* h = new qh_build();
+  h->device = device;
+  h->g = g;
+  h->reprobe_limit = reprobe_limit;
+  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete h; return qh_fail(QH_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+  h->own_stream = h->stream;
+  const size_t bytes = (size_t)8 << g.lsize;
+  e = hipMalloc((void**)&h->table, bytes);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_meta, sizeof(qh_meta));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_meta, sizeof(qh_meta), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMemsetAsync(h->table, 0, bytes, h->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(h->d_meta, 0, sizeof(qh_meta), h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) {
+    int rc = qh_fail(e == hipErrorOutOfMemory ? QH_ENOMEM : QH_EHIP, "allocating a %zu-byte table failed: %s", bytes, hipGetErrorString(e));
+    qh_build_destroy(h);
+    return rc;
+  }
+  memset(&h->st, 0, sizeof h->st);
+  h->st.slots = 1ull << g.lsize;
+  *out = h;
+  return QH_OK;
+}
+
+extern "C" void qh_build_destroy(qh_build* h) {
+  if (!h) return;
+  hipError_t e = hipSetDevice(h->device); (void)e;
+  if (h->stream) { e = hipStreamSynchronize(h->stream); (void)e; }
+  void* ptrs[] = {h->table, h->d_meta, h->d_chunk, h->d_recs, h->d_tiles, h->d_ovf[0], h->d_ovf[1], h->d_items, h->d_shard_counts};
+  for (void* p : ptrs) if (p) { e = hipFree(p); (void)e; }
+  if (h->h_meta) { e = hipHostFree(h->h_meta); (void)e; }
+  if (h->own_stream) { e = hipStreamDestroy(h->own_stream); (void)e; }
+  delete h;
+}
+
+extern "C" int qh_build_set_stream(qh_build* h, void* hip_stream) {
+  if (!h) return qh_fail(QH_EBADARG, "null handle");
+  int rc = qh_build_sync(h);
+  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  return rc;
+}
+
+// -------------------------------------------------------------- growth / sync
+
+// the table-doubling half of handle_full_ary (mer_database.hpp:142-184): allocate a
+// table of at least 2^target_lsize slots, re-insert every key carrying its value
+static int grow_table(qh_build* h, int target_lsize) {
+  uint64_t* new_table = nullptr;
+  qh_geom ng;
+  for (int lsize = target_lsize;; ++lsize) {
+    std::string err;
+    if (lsize > 44 || !qh_make_geom(h->g.k, h->g.bits, 1ull << lsize, h->g.min_qual, h->reprobe_limit,
+                                    h->g.shard_bits, h->g.shard_id, -1, ng, err))
+      return qh_fail(QH_EFULL, "Hash is full");
+    const size_t bytes = (size_t)8 << ng.lsize;
+    hipError_t e = hipMalloc((void**)&new_table, bytes);
+    if (e != hipSuccess) {  // new_keys_ allocation threw: FULL (mer_database.hpp:149-163)
+      (void)hipGetLastError();
+      return qh_fail(QH_EFULL, "Hash is full (cannot allocate a %zu-byte table: %s)", bytes, hipGetErrorString(e));
+    }
+    QH_HIP(hipMemsetAsync(new_table, 0, bytes, h->stream));
+    QH_HIP(hipMemsetAsync(h->d_meta, 0, sizeof(qh_meta), h->stream));
+    qh_launch_rehash(h->table, h->g, new_table, ng, h->d_meta, h->stream);
+    QH_HIP(hipGetLastError());
+    QH_HIP(hipMemcpyAsync(h->h_meta, h->d_meta, sizeof(qh_meta), hipMemcpyDeviceToHost, h->stream));
+    QH_HIP(hipStreamSynchronize(h->stream));
+    if (!h->h_meta->rehash_fail) break;
+    QH_HIP(hipFree(new_table));  // a key did not fit: try a bigger table
+    new_table = nullptr;
+  }
+  QH_HIP(hipFree(h->table));
+  h->table = new_table;
+  h->g = ng;
+  h->st.slots = 1ull << ng.lsize;
+  h->st.grows += 1;
+  return QH_OK;
+}
+
+// items that hit the reprobe limit wait in the overflow list; double and retry
+static int grow_and_reinsert(qh_build* h, uint64_t n_ovf) {
+  while (n_ovf) {
+    const int src = h->cur_ovf, dst = src ^ 1;
+    int rc = ensure((void**)&h->d_ovf[dst], &h->ovf_cap[dst], n_ovf * 8, "overflow list");
+    if (rc) return rc;
+    if ((rc = grow_table(h, h->g.lsize + 1))) return rc;
+    QH_HIP(hipMemsetAsync(h->d_meta, 0, sizeof(qh_meta), h->stream));
+    qh_launch_insert_items(h->d_ovf[src], n_ovf, 0, h->d_meta, h->g, h->table, h->d_ovf[dst], h->ovf_cap[dst] / 8, h->stream);
+    QH_HIP(hipGetLastError());
+    QH_HIP(hipMemcpyAsync(h->h_meta, h->d_meta, sizeof(qh_meta), hipMemcpyDeviceToHost, h->stream));
+    QH_HIP(hipStreamSynchronize(h->stream));
+    if (h->h_meta->ovf_lost) return qh_fail(QH_EFULL, "Hash is full (overflow list exhausted)");
+    h->st.distinct += h->h_meta->new_keys;
+    h->cur_ovf = dst;
+    n_ovf = h->h_meta->ovf_count;
+  }
+  return QH_OK;
+}
+
+extern "C" int qh_build_grow_to(qh_build* h, int lsize) {
+  if (!h) return qh_fail(QH_EBADARG, "null handle");
+  int rc = qh_build_sync(h);
+  if (rc) return rc;
+  QH_HIP(hipSetDevice(h->device));
+  if (h->g.lsize >= lsize) return QH_OK;
+  return grow_table(h, lsize);
+}
+
+extern "C" int qh_build_sync(qh_build* h) {
+  if (!h) return qh_fail(QH_EBADARG, "null handle");
+  if (h->failed) return qh_fail(h->failed, "%s", h->failed_msg.c_str());
+  if (!h->pending) return QH_OK;
+  QH_HIP(hipSetDevice(h->device));
+  QH_HIP(hipMemcpyAsync(h->h_meta, h->d_meta, sizeof(qh_meta), hipMemcpyDeviceToHost, h->stream));
+  QH_HIP(hipStreamSynchronize(h->stream));
+  h->pending = false;
+  const qh_meta m = *h->h_meta;
+  if (m.format_err) {
+    const char* why = (m.format_err & QH_FMT_LINES_MOD4)     ? "line count is not a multiple of 4"
+                      : (m.format_err & QH_FMT_TOO_MANY)     ? "records shorter than the fast path supports"
+                      : (m.format_err & QH_FMT_NO_AT)        ? "a record does not start with '@'"
+                      : (m.format_err & QH_FMT_NO_PLUS)      ? "a separator line does not start with '+'"
+                      : (m.format_err & QH_FMT_LEN_MISMATCH) ? "sequence and quality lengths differ"
+                                                             : "empty sequence";
+    return qh_fail(QH_EFORMAT, "chunk is not strict 4-line FASTQ (%s, near record %u); nothing was inserted", why, m.first_bad);
+  }
+  h->st.instances += m.instances;
+  h->st.hq_instances += m.hq_instances;
+  h->st.distinct += m.new_keys;
+  h->st.foreign += m.foreign;
+  h->st.records += m.nrec;
+  int rc = QH_OK;
+  if (m.ovf_lost) rc = qh_fail(QH_EFULL, "Hash is full (overflow list exhausted)");
+  else if (m.ovf_count) rc = grow_and_reinsert(h, m.ovf_count);
+  if (rc) { h->failed = rc; h->failed_msg = g_last_error; }
+  return rc;
+}
+
+static int begin_chunk(qh_build* h, size_t max_items) {
+  int rc = qh_build_sync(h);
+  if (rc) return rc;
+  QH_HIP(hipSetDevice(h->device));
+  rc = ensure((void**)&h->d_ovf[h->cur_ovf], &h->ovf_cap[h->cur_ovf], (max_items + 1) * 8, "overflow list");
+  if (rc) return rc;
+  QH_HIP(hipMemsetAsync(h->d_meta, 0, sizeof(qh_meta), h->stream));
+  return QH_OK;
+}
+
+// ------------------------------------------------------------------ inputs
+
+static const size_t kMaxChunk = 0xFFFFF000ull;  // 32-bit offsets inside a chunk
+
+extern "C" int qh_build_add_fastq_device(qh_build* h, const void* dev_buf, size_t len) {
+  if (!h) return qh_fail(QH_EBADARG, "null handle");
+  if (len == 0) return QH_OK;
+  if (!dev_buf || ((uintptr_t)dev_buf & 15)) return qh_fail(QH_EBADARG, "device chunk must be non-null and 16-byte aligned");
+  if (len > kMaxChunk) return qh_fail(QH_EBADARG, "chunk larger than %zu bytes", kMaxChunk);
+  int rc = begin_chunk(h, len / 2);
+  if (rc) return rc;
+  const size_t ntiles = (len + QH_TILE_BYTES - 1) / QH_TILE_BYTES;
+  const size_t rec_cap = len / 16 + 16;
+  if ((rc = ensure((void**)&h->d_tiles, &h->tile_cap, (ntiles + 1) * 4, "tile counts"))) return rc;
+  if ((rc = ensure((void**)&h->d_recs, &h->rec_cap, rec_cap * 16, "record table"))) return rc;
+  qh_launch_index_fastq((const uint8_t*)dev_buf, len, h->d_tiles, h->d_recs, (uint32_t)rec_cap, h->d_meta, h->stream);
+  qh_launch_build_direct((const uint8_t*)dev_buf, h->d_recs, h->d_meta, h->g, h->table, h->d_ovf[h->cur_ovf],
+                         h->ovf_cap[h->cur_ovf] / 8, h->stream);
+  QH_HIP(hipGetLastError());
+  h->pending = true;
+  return QH_OK;
+}
+
+static int stage_chunk(qh_build* h, const char* buf, size_t len, const char* extra, size_t extra_len, size_t* extra_off) {
+  const size_t eo = (len + 15) & ~(size_t)15;
+  int rc = ensure((void**)&h->d_chunk, &h->chunk_cap, eo + extra_len + 16, "chunk staging");
+  if (rc) return rc;
+  QH_HIP(hipMemcpyAsync(h->d_chunk, buf, len, hipMemcpyHostToDevice, h->stream));
+  if (extra_len) QH_HIP(hipMemcpyAsync(h->d_chunk + eo, extra, extra_len, hipMemcpyHostToDevice, h->stream));
+  if (extra_off) *extra_off = eo;
+  return QH_OK;
+}
+
+extern "C" int qh_build_add_fastq(qh_build* h, const char* buf, size_t len) {
+  if (!h) return qh_fail(QH_EBADARG, "null handle");
+  if (len == 0) return QH_OK;
+  if (!buf) return qh_fail(QH_EBADARG, "null chunk");
+  if (len > kMaxChunk) return qh_fail(QH_EBADARG, "chunk larger than %zu bytes", kMaxChunk);
+  int rc = qh_build_sync(h);  // the staging buffer is reused: previous chunk must be done
+  if (rc) return rc;
+  QH_HIP(hipSetDevice(h->device));
+  if ((rc = stage_chunk(h, buf, len, nullptr, 0, nullptr))) return rc;
+  // pageable source: the copy must have consumed `buf` before we return
+  QH_HIP(hipStreamSynchronize(h->stream));
+  return qh_build_add_fastq_device(h, h->d_chunk, len);
+}
+
+static int submit_records(qh_build* h, const uint8_t* dev_buf, const qh_record* recs, size_t nrec, size_t max_items) {
+  int rc = begin_chunk(h, max_items);
+  if (rc) return rc;
+  if ((rc = ensure((void**)&h->d_recs, &h->rec_cap, (nrec + 1) * 16, "record table"))) return rc;
+  static_assert(sizeof(qh_record) == 16, "qh_record must match the device record");
+  QH_HIP(hipMemcpyAsync(h->d_recs, recs, nrec * 16, hipMemcpyHostToDevice, h->stream));
+  const uint32_t n32 = (uint32_t)nrec;
+  QH_HIP(hipMemcpyAsync(&h->d_meta->nrec, &n32, 4, hipMemcpyHostToDevice, h->stream));
+  QH_HIP(hipStreamSynchronize(h->stream));  // recs / n32 are caller / stack memory
+  qh_launch_build_direct(dev_buf, h->d_recs, h->d_meta, h->g, h->table, h->d_ovf[h->cur_ovf],
+                         h->ovf_cap[h->cur_ovf] / 8, h->stream);
+  QH_HIP(hipGetLastError());
+  h->pending = true;
+  return QH_OK;
+}
+
+extern "C" int qh_build_add_records_device(qh_build* h, const void* dev_buf, size_t len, const qh_record* recs, size_t nrec) {
+  if (!h) return qh_fail(QH_EBADARG, "null handle");
+  if (nrec == 0) return QH_OK;
+  if (!dev_buf || !recs) return qh_fail(QH_EBADARG, "null buffer");
+  if (len > kMaxChunk || nrec > 0xFFFFFFFFull) return qh_fail(QH_EBADARG, "chunk too large");
+  size_t total = 0;
+  for (size_t i = 0; i < nrec; ++i) {
+    if ((size_t)recs[i].seq_off + recs[i].len > len || (size_t)recs[i].qual_off + recs[i].len > len)
+      return qh_fail(QH_EBADARG, "record %zu lies outside the chunk", i);
+    total += recs[i].len;
+  }
+  return submit_records(h, (const uint8_t*)dev_buf, recs, nrec, total);
+}
+
+// Sequential parser with jellyfish::whole_sequence_parser's FASTQ rules. Returns
+// QH_OK and the records of every COMPLETE record; *consumed = bytes they span.
+// Multi-line records are re-flowed into `scratch` (offsets relative to scratch_base).
+static int parse_fastq_host(const char* buf, size_t len, bool final_chunk, std::vector<qh_record>& recs,
+                            std::string& scratch, size_t* consumed) {
+  size_t p = 0;
+  *consumed = 0;
+  auto eol = [&](size_t from) -> size_t {
+    const void* e = from < len ? memchr(buf + from, '\n', len - from) : nullptr;
+    return e ? (size_t)((const char*)e - buf) : len;
+  };
+  while (p < len) {
+    if (buf[p] != '@')
+      return p == 0 ? qh_fail(QH_EFORMAT, "Unsupported format: the chunk does not start with '@' (FASTA input has no qualities)")
+                    : qh_fail(QH_EFORMAT, "Invalid fastq file: header missing");
+    size_t e = eol(p);
+    if (e >= len) { if (final_chunk) return qh_fail(QH_EFORMAT, "Truncated fastq file"); break; }
+    size_t q = e + 1;
+    // sequence lines up to the '+' line
+    const size_t seq_first = q;
+    size_t slen = 0, nlines = 0, first_len = 0, spos = scratch.size();
+    bool incomplete = false;
+    for (;;) {
+      if (q >= len) { incomplete = true; break; }
+      if (buf[q] == '+') break;
+      e = eol(q);
+      if (e >= len && !final_chunk) { incomplete = true; break; }
+      const size_t l = e - q;
+      if (nlines == 0) first_len = l;
+      if (nlines == 1) scratch.append(buf + seq_first, first_len);
+      if (nlines >= 1) scratch.append(buf + q, l);
+      slen += l; ++nlines;
+      q = e < len ? e + 1 : len;
+    }
+    if (incomplete) { scratch.resize(spos); if (final_chunk) return qh_fail(QH_EFORMAT, "Truncated fastq file"); break; }
+    const bool seq_multi = nlines > 1;
+    // the '+' line
+    e = eol(q);
+    bool good = e < len;
+    if (!good && !final_chunk) { scratch.resize(spos); break; }
+    q = good ? e + 1 : len;
+    // quality lines until qual.size() >= seq.size()
+    const size_t qual_first = q, qspos = scratch.size();
+    size_t qlen = 0, qlines = 0, qfirst = 0;
+    incomplete = false;
+    while (qlen < slen && good) {
+      if (q >= len) { good = false; if (!final_chunk) incomplete = true; break; }
+      e = eol(q);
+      if (e >= len) { if (!final_chunk) { incomplete = true; break; } good = false; }
+      const size_t l = e - q;
+      if (qlines == 0) qfirst = l;
+      if (qlines == 1) scratch.append(buf + qual_first, qfirst);
+      if (qlines >= 1) scratch.append(buf + q, l);
+      qlen += l; ++qlines;
+      q = e < len ? e + 1 : len;
+    }
+    if (incomplete) { scratch.resize(spos); break; }
+    if (qlen != slen) return qh_fail(QH_EFORMAT, "Invalid fastq file: wrong number of quals");
+    if (q < len && buf[q] != '@') return qh_fail(QH_EFORMAT, "Invalid fastq file: header missing");
+    if (slen > 0xFFFFFFFFull) return qh_fail(QH_EFORMAT, "read longer than 4 Gbases");
+    const bool qual_multi = qlines > 1;
+    qh_record r;
+    r.len = (uint32_t)slen;
+    // offsets into the scratch area are fixed up by the caller once its base is
+    // known; reserved bit 0 / bit 1 mark a re-flowed sequence / quality
+    r.seq_off = (uint32_t)(seq_multi ? spos : seq_first);
+    r.qual_off = (uint32_t)(qual_multi ? qspos : qual_first);
+    r.reserved = (seq_multi ? 1u : 0u) | (qual_multi ? 2u : 0u);
+    recs.push_back(r);
+    p = q;
+    *consumed = p;
+  }
+  return QH_OK;
+}
+
+extern "C" int qh_build_add_fastq_host_parsed(qh_build* h, const char* buf, size_t len, int final_chunk, size_t* consumed) {
+  if (!h) return qh_fail(QH_EBADARG, "null handle");
+  if (consumed) *consumed = 0;
+  if (len == 0) return QH_OK;
+  if (!buf) return qh_fail(QH_EBADARG, "null chunk");
+  if (len > kMaxChunk / 2) return qh_fail(QH_EBADARG, "chunk larger than %zu bytes", kMaxChunk / 2);
+  std::vector<qh_record> recs;
+  std::string scratch;
+  size_t used = 0;
+  int rc = parse_fastq_host(buf, len, final_chunk != 0, recs, scratch, &used);
+  if (rc) return rc;
+  if (consumed) *consumed = used;
+  if (recs.empty()) return QH_OK;
+  if ((rc = qh_build_sync(h))) return rc;
+  QH_HIP(hipSetDevice(h->device));
+  size_t extra_off = 0;
+  if ((rc = stage_chunk(h, buf, used, scratch.data(), scratch.size(), &extra_off))) return rc;
+  size_t total = 0;
+  for (size_t i = 0; i < recs.size(); ++i) {
+    if (recs[i].reserved & 1u) recs[i].seq_off += (uint32_t)extra_off;
+    if (recs[i].reserved & 2u) recs[i].qual_off += (uint32_t)extra_off;
+    recs[i].reserved = 0;
+    total += recs[i].len;
+  }
+  QH_HIP(hipStreamSynchronize(h->stream));
+  return submit_records(h, h->d_chunk, recs.data(), recs.size(), total);
+}
+
+extern "C" int qh_build_add_mers_device(qh_build* h, const uint64_t* dev_items, size_t n) {
+  if (!h) return qh_fail(QH_EBADARG, "null handle");
+  if (n == 0) return QH_OK;
+  if (!dev_items) return qh_fail(QH_EBADARG, "null items");
+  int rc = begin_chunk(h, n);
+  if (rc) return rc;
+  qh_launch_insert_items(dev_items, n, 1, h->d_meta, h->g, h->table, h->d_ovf[h->cur_ovf], h->ovf_cap[h->cur_ovf] / 8, h->stream);
+  QH_HIP(hipGetLastError());
+  h->pending = true;
+  return QH_OK;
+}
+
+extern "C" int qh_build_add_mers(qh_build* h, const uint64_t* mers, const uint8_t* quality, size_t n) {
+  if (!h) return qh_fail(QH_EBADARG, "null handle");
+  if (n == 0) return QH_OK;
+  if (!mers || !quality) return qh_fail(QH_EBADARG, "null input");
+  std::vector<uint64_t> items(n);
+  for (size_t i = 0; i < n; ++i) {
+    if (mers[i] & ~h->g.kmask) return qh_fail(QH_EBADARG, "mer %zu has bits above 2k", i);
+    items[i] = (mers[i] << 1) | (quality[i] ? 1u : 0u);
+  }
+  int rc = qh_build_sync(h);
+  if (rc) return rc;
+  QH_HIP(hipSetDevice(h->device));
+  if ((rc = ensure((void**)&h->d_items, &h->items_cap, n * 8, "item staging"))) return rc;
+  QH_HIP(hipMemcpyAsync(h->d_items, items.data(), n * 8, hipMemcpyHostToDevice, h->stream));
+  QH_HIP(hipStreamSynchronize(h->stream));
+  return qh_build_add_mers_device(h, h->d_items, n);
+}
+
+extern "C" int qh_build_extract_partitioned_device(qh_build* h, const void* dev_buf, size_t len, uint64_t* dev_out,
+                                                   uint64_t cap_per_shard, uint64_t* dev_counts) {
+  if (!h) return qh_fail(QH_EBADARG, "null handle");
+  if (!dev_out || !dev_counts) return qh_fail(QH_EBADARG, "null output");
+  if (len && (!dev_buf || ((uintptr_t)dev_buf & 15))) return qh_fail(QH_EBADARG, "device chunk must be 16-byte aligned");
+  if (len > kMaxChunk) return qh_fail(QH_EBADARG, "chunk larger than %zu bytes", kMaxChunk);
+  int rc = qh_build_sync(h);
+  if (rc) return rc;
+  QH_HIP(hipSetDevice(h->device));
+  QH_HIP(hipMemsetAsync(dev_counts, 0, sizeof(uint64_t) << h->g.shard_bits, h->stream));
+  if (len == 0) return QH_OK;
+  QH_HIP(hipMemsetAsync(h->d_meta, 0, sizeof(qh_meta), h->stream));
+  const size_t ntiles = (len + QH_TILE_BYTES - 1) / QH_TILE_BYTES;
+  const size_t rec_cap = len / 16 + 16;
+  if ((rc = ensure((void**)&h->d_tiles, &h->tile_cap, (ntiles + 1) * 4, "tile counts"))) return rc;
+  if ((rc = ensure((void**)&h->d_recs, &h->rec_cap, rec_cap * 16, "record table"))) return rc;
+  qh_launch_index_fastq((const uint8_t*)dev_buf, len, h->d_tiles, h->d_recs, (uint32_t)rec_cap, h->d_meta, h->stream);
+  qh_launch_extract_partitioned((const uint8_t*)dev_buf, h->d_recs, h->d_meta, h->g, dev_out, cap_per_shard,
+                                (unsigned long long*)dev_counts, h->stream);
+  QH_HIP(hipGetLastError());
+  // format / capacity verdict of this call
+  QH_HIP(hipMemcpyAsync(h->h_meta, h->d_meta, sizeof(qh_meta), hipMemcpyDeviceToHost, h->stream));
+  QH_HIP(hipStreamSynchronize(h->stream));
+  if (h->h_meta->format_err) return qh_fail(QH_EFORMAT, "chunk is not strict 4-line FASTQ (flags 0x%x near record %u)", h->h_meta->format_err, h->h_meta->first_bad);
+  if (h->h_meta->ovf_lost) return qh_fail(QH_EBADARG, "cap_per_shard too small for this chunk");
+  h->st.records += h->h_meta->nrec;
+  return QH_OK;
+}
+
+// -------------------------------------------------------------------- outputs
+
+extern "C" int qh_build_get_stats(qh_build* h, qh_build_stats* stats) {
+  if (!h || !stats) return qh_fail(QH_EBADARG, "null argument");
+  int rc = qh_build_sync(h);
+  *stats = h->st;
+  return rc;
+}
+
+extern "C" int qh_build_finish(qh_build* h, qh_build_stats* stats) {
+  if (!h) return qh_fail(QH_EBADARG, "null handle");
+  int rc = qh_build_sync(h);
+  if (stats) *stats = h->st;
+  return rc;
+}
+
+extern "C" int qh_build_reset(qh_build* h) {
+  if (!h) return qh_fail(QH_EBADARG, "null handle");
+  if (h->pending) { int rc = qh_build_sync(h); if (rc && rc != QH_EFORMAT) return rc; }
+  QH_HIP(hipSetDevice(h->device));
+  QH_HIP(hipMemsetAsync(h->table, 0, (size_t)8 << h->g.lsize, h->stream));
+  const uint64_t slots = h->st.slots, grows = h->st.grows;
+  memset(&h->st, 0, sizeof h->st);
+  h->st.slots = slots; h->st.grows = grows;
+  h->failed = 0;
+  return QH_OK;
+}
+
+static int write_all(int fd, const void* p, size_t n, off_t off) {
+  const char* c = (const char*)p;
+  while (n) {
+    ssize_t w = pwrite(fd, c, n, off);
+    if (w < 0) { if (errno == EINTR) continue; return -1; }
+    c += w; n -= (size_t)w; off += w;
+  }
+  return 0;
+}
+
+extern "C" int qh_build_write(qh_build* h, const char* path, int argc, const char* const* argv) {
+  if (!h || !path) return qh_fail(QH_EBADARG, "null argument");
+  int rc = qh_build_sync(h);
+  if (rc) return rc;
+  if (h->g.shard_bits) return qh_fail(QH_EBADARG, "qh_build_write on a sharded handle: use qh_build_write_shard");
+  return qh_build_write_shard(h, path, argc, argv, 1);
+}
+
+// Every shard writes its slice of the keys image; values are packed per shard into
+// the global atomic_bits_array image (word-aligned when slots % vpw == 0, else the
+// shard owner ORs its fields into shared boundary words -- single writer at a time).
+extern "C" int qh_build_write_shard(qh_build* h, const char* path, int argc, const char* const* argv, int write_header) {
+  if (!h || !path) return qh_fail(QH_EBADARG, "null argument");
+  int rc = qh_build_sync(h);
+  if (rc) return rc;
+  QH_HIP(hipSetDevice(h->device));
+  qh_file_header fh;
+  qh_header_from_geom(h->g, fh);
+  qh_header_fill_standard(fh, argc, argv);
+  std::string hdr;
+  qh_header_serialize(fh, hdr);
+  int fd = open(path, write_header ? (O_WRONLY | O_CREAT | O_TRUNC) : O_WRONLY, 0644);
+  if (fd < 0) return qh_fail(QH_EIO, "Failed to open output file '%s'.", path);  // create_database.cc:113-115
+  bool ok = true;
+  if (write_header) {
+    ok = write_all(fd, hdr.data(), hdr.size(), 0) == 0;
+    // extend to the final length so that shards can pwrite in any order
+    if (ok) ok = ftruncate(fd, (off_t)(fh.offset + fh.key_bytes + fh.value_bytes)) == 0;
+  } else {
+    // offset depends on the header text (hostname, cmdline...): read it back from the file
+    qh_file_header on_disk;
+    std::string err;
+    if (!qh_header_read_file(path, on_disk, err)) { close(fd); return qh_fail(QH_EIO, "%s", err.c_str()); }
+    fh.offset = on_disk.offset;
+  }
+  const uint64_t slots = 1ull << h->g.lsize;
+  const uint64_t first = (uint64_t)h->g.shard_id * slots;
+  const size_t piece = (size_t)1 << 23;  // slots per staging piece (64 MiB)
+  std::vector<uint64_t> stage(slots < piece ? slots : piece);
+  const int vbits = h->g.vbits;
+  const uint64_t vpw = 64 / vbits;
+  const uint64_t w0 = first / vpw, w1 = (first + slots + vpw - 1) / vpw;  // value words touched by this shard
+  std::vector<uint64_t> vimg(w1 - w0, 0);
+  for (uint64_t at = 0; ok && at < slots; at += stage.size()) {
+    const uint64_t n = slots - at < stage.size() ? slots - at : stage.size();
+    hipError_t e = hipMemcpyAsync(stage.data(), h->table + at, n * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { close(fd); return qh_fail(QH_EHIP, "reading the table back failed: %s", hipGetErrorString(e)); }
+    ok = write_all(fd, stage.data(), n * 8, (off_t)(fh.offset + (first + at) * 8)) == 0;
+    const uint64_t vmask = h->g.vmask;
+    for (uint64_t i = 0; i < n; ++i) {
+      const uint64_t v = stage[i] & vmask;
+      if (!v) continue;
+      const uint64_t gi = first + at + i;
+      vimg[gi / vpw - w0] |= v << ((gi % vpw) * vbits);
+    }
+  }
+  if (ok) {
+    const off_t voff = (off_t)(fh.offset + fh.key_bytes + w0 * 8);
+    if (h->g.shard_bits && (first % vpw || (first + slots) % vpw)) {
+      // boundary words are shared with the neighbouring shards: OR into what is there
+      uint64_t edge;
+      if (pread(fd, &edge, 8, voff) == 8) vimg.front() |= edge;
+      if (vimg.size() > 1 && pread(fd, &edge, 8, voff + (off_t)(vimg.size() - 1) * 8) == 8) vimg.back() |= edge;
+    }
+    ok = write_all(fd, vimg.data(), vimg.size() * 8, voff) == 0;
+  }
+  if (close(fd) != 0) ok = false;
+  if (!ok) return qh_fail(QH_EIO, "Failed to write output file '%s': %s", path, strerror(errno));
+  return QH_OK;
+}
+
+extern "C" int qh_build_dump(qh_build* h, uint64_t* mers, uint64_t* vals, uint64_t cap, uint64_t* n) {
+  if (!h || !n) return qh_fail(QH_EBADARG, "null argument");
+  int rc = qh_build_sync(h);
+  if (rc) return rc;
+  return qh_table_dump(h->device, h->stream, h->table, h->g, h->d_meta, h->h_meta, mers, vals, cap, n);
+}
+
+extern "C" int qh_build_as_query(qh_build* h, qh_query** out) {
+  if (!h || !out) return qh_fail(QH_EBADARG, "null argument");
+  int rc = qh_build_sync(h);
+  if (rc) return rc;
+  if (h->g.shard_bits) return qh_fail(QH_EBADARG, "a sharded build handle cannot serve lookups on its own");
+  return qh_query_from_table(h->device, h->table, h->g, out);
+}
+
+// number of leading bytes of buf that form whole groups of 4 lines (the chunk cut
+// used by the CLI's fast path); a last line without '\n' counts only when `final_chunk`
+extern "C" size_t qh_fastq_4line_prefix(const char* buf, size_t len, int final_chunk) {
+  size_t lines = 0, pos = 0, last_group_end = 0;
+  while (pos < len) {
+    const void* e = memchr(buf + pos, '\n', len - pos);
+    if (!e) {
+      if (final_chunk && ((lines + 1) & 3) == 0) last_group_end = len;
+      break;
+    }
+    pos = (size_t)((const char*)e - buf) + 1;
+    if ((++lines & 3) == 0) last_group_end = pos;
+  }
+  return last_group_end;
+}

@@ -1,0 +1,51 @@
+// qh_internal.h -- handle definitions shared by qh_build.hip and qh_query.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <string>
+#include "qh_host.h"
+#include "qh_kernels.h"
+
+struct qh_build {
+  int device = 0;
+  hipStream_t stream = nullptr;      // stream all work is enqueued on
+  hipStream_t own_stream = nullptr;  // the handle's own stream
+  qh_geom g;
+  int reprobe_limit = 126;
+  uint64_t* table = nullptr;
+  uint8_t* d_chunk = nullptr;  size_t chunk_cap = 0;  // staging of host-fed chunks
+  uint4* d_recs = nullptr;     size_t rec_cap = 0;    // record table of the chunk
+  uint32_t* d_tiles = nullptr; size_t tile_cap = 0;   // newline counts / prefix per tile
+  uint64_t* d_ovf[2] = {nullptr, nullptr}; size_t ovf_cap[2] = {0, 0};  // overflow lists (bytes)
+  uint64_t* d_items = nullptr; size_t items_cap = 0;  // staging of host-fed items
+  uint64_t* d_shard_counts = nullptr;
+  int cur_ovf = 0;
+  qh_meta* d_meta = nullptr;
+  qh_meta* h_meta = nullptr;  // pinned mirror
+  qh_build_stats st;
+  bool pending = false;       // kernels of a chunk are in flight, meta not yet collected
+  int failed = 0;             // sticky fatal status (QH_EFULL ...)
+  std::string failed_msg;
+};
+
+struct qh_query {
+  int device = 0;
+  qh_geom g;
+  uint64_t* table = nullptr;
+  bool owns_table = true;
+  hipStream_t stream = nullptr;
+  qh_meta* d_meta = nullptr;
+  qh_meta* h_meta = nullptr;
+  // staging for the host-pointer entry points
+  void* d_in = nullptr;  size_t in_cap = 0;
+  void* d_in2 = nullptr; size_t in2_cap = 0;
+  void* d_out = nullptr; size_t out_cap = 0;
+  std::mutex mu;
+};
+
+int qh_query_from_table(int device, uint64_t* table, const qh_geom& g, qh_query** out);
+int qh_table_dump(int device, hipStream_t stream, const uint64_t* table, const qh_geom& g, qh_meta* d_meta,
+                  qh_meta* h_meta, uint64_t* mers, uint64_t* vals, uint64_t cap, uint64_t* n);
+int qh_ensure_device(void** p, size_t* cap, size_t need, const char* what);
+
+extern "C" int qh_build_write_shard(qh_build* h, const char* path, int argc, const char* const* argv, int write_header);

@@ -1,0 +1,67 @@
+// qh_kernels.h -- launchers of the gfx950 kernels (qh_kernels.hip). Internal to
+// libquorum_hip; the public surface is include/quorum_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "qh_spec.h"
+
+// Device-resident per-chunk state; mirrored to pinned host memory by qh_build_sync.
+struct qh_meta {
+  uint32_t n_lines;      // lines found in the chunk (incl. a virtual last newline)
+  uint32_t nrec;         // records of the chunk
+  uint32_t format_err;   // != 0: chunk is not strict 4-line FASTQ; nothing inserted
+  uint32_t first_bad;    // smallest offending record / line index
+  uint32_t ovf_lost;     // != 0: overflow list itself overflowed (fatal)
+  uint32_t rehash_fail;  // != 0: a key did not fit the grown table
+  uint64_t ovf_count;    // items that hit the reprobe limit (waiting for growth)
+  uint64_t instances;    // counted_low
+  uint64_t hq_instances; // counted_high
+  uint64_t new_keys;     // slots claimed
+  uint64_t foreign;      // items owned by another shard (dropped)
+  uint64_t dump_count;   // cursor of k_dump
+  uint64_t stat_distinct, stat_total;
+};
+
+enum { QH_FMT_LINES_MOD4 = 1, QH_FMT_NO_AT = 2, QH_FMT_NO_PLUS = 4, QH_FMT_LEN_MISMATCH = 8,
+       QH_FMT_TOO_MANY = 16, QH_FMT_EMPTY_TAIL = 32 };
+
+#define QH_TILE_BYTES 16384u
+
+// --- FASTQ chunk -> record table -------------------------------------------------
+// rec_cap = capacity of `recs` in records. tile_counts has ceil(len/QH_TILE_BYTES)+1 entries.
+void qh_launch_index_fastq(const uint8_t* buf, size_t len, uint32_t* tile_counts, uint4* recs,
+                           uint32_t rec_cap, qh_meta* meta, hipStream_t s);
+
+// --- record table -> k-mers -> table (direct global-CAS build) --------------------
+void qh_launch_build_direct(const uint8_t* buf, const uint4* recs, qh_meta* meta, const qh_geom& g,
+                            uint64_t* table, uint64_t* ovf, uint64_t ovf_cap, hipStream_t s);
+
+// packed items (mer<<1|q) -> table. count_instances = 0 when re-inserting the
+// overflow list (those items were counted when first seen).
+void qh_launch_insert_items(const uint64_t* items, uint64_t n, int count_instances, qh_meta* meta,
+                            const qh_geom& g, uint64_t* table, uint64_t* ovf, uint64_t ovf_cap,
+                            hipStream_t s);
+
+// old table -> new (empty) table, carrying the value fields (mer_database.hpp:165-176)
+void qh_launch_rehash(const uint64_t* old_table, const qh_geom& og, uint64_t* new_table,
+                      const qh_geom& ng, qh_meta* meta, hipStream_t s);
+
+// record table -> items bucketed by owner shard (multi-GPU exchange front end)
+void qh_launch_extract_partitioned(const uint8_t* buf, const uint4* recs, qh_meta* meta,
+                                   const qh_geom& g, uint64_t* out, uint64_t cap_per_shard,
+                                   unsigned long long* counts, hipStream_t s);
+
+// --- read side ------------------------------------------------------------------------
+void qh_launch_lookup(const uint64_t* table, const qh_geom& g, const uint64_t* mers, uint64_t n,
+                      uint64_t* out, int get_val, hipStream_t s);
+void qh_launch_best_alternatives(const uint64_t* table, const qh_geom& g, const uint64_t* fmers,
+                                 const uint8_t* backward, uint64_t n, uint64_t* counts,
+                                 int32_t* ucode, int32_t* level, int32_t* nkept, hipStream_t s);
+void qh_launch_stats(const uint64_t* table, const qh_geom& g, qh_meta* meta, hipStream_t s);
+void qh_launch_histo(const uint64_t* table, const qh_geom& g, unsigned long long* histo, hipStream_t s);
+void qh_launch_dump(const uint64_t* table, const qh_geom& g, uint64_t* mers, uint64_t* vals,
+                    uint64_t cap, qh_meta* meta, hipStream_t s);
+
+// --- roofline microbenchmarks -------------------------------------------------------
+void qh_launch_random_access(uint64_t* table, int lsize, uint64_t n, int mode, uint64_t seed,
+                             unsigned long long* sink, hipStream_t s);

@@ -1,0 +1,673 @@
+// qh_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of libquorum_hip.
+//
+// Hot path replaced (paths relative to the Quorum tree):
+//   FASTQ chunk -> records            jellyfish::whole_sequence_parser, src/create_database.cc:52,61-66
+//   per-base rolling canonical k-mer  src/create_database.cc:64-92
+//   hash_with_quality::add            src/mer_database.hpp:94-113
+//   table doubling / rehash           src/mer_database.hpp:137-187
+//   database_query lookups            src/mer_database.hpp:284-329
+//   table reductions                  src/error_correct_reads.cc:650-659, src/histo_mer_database.cc:13-21
+//
+// Everything here is integer/byte work bound by HBM (random 8-byte slot updates
+// plus a streaming pass over the chunk); there is no MFMA-shaped work.
+#include "qh_kernels.h"
+
+#define QH_BLOCK 256
+
+// ------------------------------------------------------------------ small helpers
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
+  // number of set bits of `mask` in lanes below the calling lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+}
+
+// 16-bit mask of the bytes of v that equal '\n'
+__device__ __forceinline__ uint32_t nl_mask16(uint4 v) {
+  uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  uint32_t m = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t x = w[i] ^ 0x0A0A0A0Au;
+    const uint32_t t = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);  // 0x80 at zero bytes
+    const uint32_t c = ((t >> 7) & 1u) | ((t >> 14) & 2u) | ((t >> 21) & 4u) | ((t >> 28) & 8u);
+    m |= c << (4 * i);
+  }
+  return m;
+}
+
+// 16 bytes at off (off is a multiple of 16; buf is 16-byte aligned); bytes past len read as 0
+__device__ __forceinline__ uint4 load16_guarded(const uint8_t* __restrict__ buf, size_t off, size_t len) {
+  if (off + 16 <= len) return *reinterpret_cast<const uint4*>(buf + off);
+  uint32_t w[4] = {0, 0, 0, 0};
+  for (int i = 0; i < 16; ++i)
+    if (off + i < len) w[i >> 2] |= (uint32_t)buf[off + i] << (8 * (i & 3));
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ------------------------------------------------------- FASTQ chunk -> record table
+
+// pass 1: newlines per 16 KiB tile
+__global__ __launch_bounds__(QH_BLOCK) void k_count_newlines(const uint8_t* __restrict__ buf, size_t len,
+                                                             uint32_t* __restrict__ tile_counts) {
+  __shared__ uint32_t wsum[QH_BLOCK / 64];
+  const size_t tile_base = (size_t)blockIdx.x * QH_TILE_BYTES;
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const size_t off = tile_base + ((size_t)j * QH_BLOCK + threadIdx.x) * 16;
+    if (off < len) cnt += __popc(nl_mask16(load16_guarded(buf, off, len)));
+  }
+  cnt = wave_sum_u32(cnt);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// pass 2: exclusive scan of the tile counts (one workgroup), chunk-level checks
+__global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ tile_counts, uint32_t ntiles,
+                                                     const uint8_t* __restrict__ buf, size_t len,
+                                                     uint32_t rec_cap, qh_meta* __restrict__ meta) {
+  __shared__ uint32_t part[1024];
+  const uint32_t per = (ntiles + 1023) / 1024;
+  const uint32_t b = threadIdx.x * per;
+  uint32_t s = 0;
+  for (uint32_t i = b; i < b + per && i < ntiles; ++i) s += tile_counts[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  // Hillis-Steele inclusive scan over 1024 partials
+  for (uint32_t o = 1; o < 1024; o <<= 1) {
+    uint32_t v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - s;  // exclusive prefix of this thread's span
+  for (uint32_t i = b; i < b + per && i < ntiles; ++i) {
+    const uint32_t c = tile_counts[i];
+    tile_counts[i] = run;
+    run += c;
+  }
+  if (threadIdx.x == 1023) {
+    uint32_t lines = part[1023];
+    if (len > 0 && buf[len - 1] != '\n') ++lines;  // last line without '\n'
+    uint32_t err = 0;
+    if (lines & 3u) err |= QH_FMT_LINES_MOD4;
+    if ((lines >> 2) > rec_cap) err |= QH_FMT_TOO_MANY;
+    if (len > 0 && buf[0] != '@') err |= QH_FMT_NO_AT;
+    meta->n_lines = lines;
+    meta->nrec = err ? 0 : (lines >> 2);
+    meta->format_err = err;
+    meta->first_bad = err ? 0 : 0xFFFFFFFFu;
+  }
+}
+
+// a newline at byte p ends line L: fill the matching field of record L/4 and
+// check the first byte of line L+1 ('@' for a header line, '+' for a separator)
+__device__ __forceinline__ void line_end(const uint8_t* __restrict__ buf, size_t len, uint32_t L,
+                                         uint32_t p, uint32_t* __restrict__ recs, uint32_t rec_cap,
+                                         qh_meta* __restrict__ meta) {
+  const uint32_t r = L >> 2, t = L & 3u;
+  if (r < rec_cap) recs[4 * (size_t)r + t] = (t & 1u) ? p : p + 1;  // x=seq_off y=seq_end z=qual_off w=qual_end
+  if ((size_t)p + 1 < len) {
+    const uint32_t nt = (L + 1) & 3u;
+    const uint8_t c = buf[p + 1];
+    if (nt == 0 && c != '@') { atomicOr(&meta->format_err, QH_FMT_NO_AT); atomicMin(&meta->first_bad, (L + 1) >> 2); }
+    if (nt == 2 && c != '+') { atomicOr(&meta->format_err, QH_FMT_NO_PLUS); atomicMin(&meta->first_bad, (L + 1) >> 2); }
+  }
+}
+
+// pass 3: every newline writes its field of the record table
+__global__ __launch_bounds__(QH_BLOCK) void k_fill_records(const uint8_t* __restrict__ buf, size_t len,
+                                                           const uint32_t* __restrict__ tile_prefix,
+                                                           uint32_t* __restrict__ recs, uint32_t rec_cap,
+                                                           qh_meta* __restrict__ meta) {
+  __shared__ uint32_t wtot[QH_BLOCK / 64];
+  if (meta->format_err & (QH_FMT_LINES_MOD4 | QH_FMT_TOO_MANY)) return;
+  const size_t tile_base = (size_t)blockIdx.x * QH_TILE_BYTES;
+  uint32_t run = tile_prefix[blockIdx.x];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll 1
+  for (int j = 0; j < 4; ++j) {
+    const size_t off = tile_base + ((size_t)j * QH_BLOCK + threadIdx.x) * 16;
+    uint32_t m = off < len ? nl_mask16(load16_guarded(buf, off, len)) : 0;
+    const uint32_t c = __popc(m);
+    // block exclusive scan of c
+    uint32_t inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      uint32_t v = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += v;
+    }
+    if (lane == 63) wtot[wv] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < QH_BLOCK / 64; ++w) {
+      const uint32_t x = wtot[w];
+      if (w < wv) wbase += x;
+      tot += x;
+    }
+    uint32_t L = run + wbase + inc - c;
+    while (m) {
+      const int bpos = __ffs(m) - 1;
+      m &= m - 1;
+      line_end(buf, len, L++, (uint32_t)(off + bpos), recs, rec_cap, meta);
+    }
+    run += tot;
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && len > 0 && buf[len - 1] != '\n')
+    line_end(buf, len, meta->n_lines - 1, (uint32_t)len, recs, rec_cap, meta);
+}
+
+// pass 4: length checks; rewrites each record to {seq_off, len, qual_off, 0}
+__global__ __launch_bounds__(QH_BLOCK) void k_validate_records(uint4* __restrict__ recs, qh_meta* __restrict__ meta) {
+  const uint32_t nrec = meta->nrec;
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nrec; r += gridDim.x * blockDim.x) {
+    const uint4 rc = recs[r];
+    const uint32_t slen = rc.y - rc.x, qlen = rc.w - rc.z;
+    if (rc.y < rc.x || rc.w < rc.z || slen != qlen) {
+      atomicOr(&meta->format_err, QH_FMT_LEN_MISMATCH);
+      atomicMin(&meta->first_bad, r);
+    } else if (slen == 0) {  // upstream's parser does not consume the empty quality line
+      atomicOr(&meta->format_err, QH_FMT_EMPTY_TAIL);
+      atomicMin(&meta->first_bad, r);
+    }
+    recs[r] = make_uint4(rc.x, slen, rc.z, 0);
+  }
+}
+
+void qh_launch_index_fastq(const uint8_t* buf, size_t len, uint32_t* tile_counts, uint4* recs,
+                           uint32_t rec_cap, qh_meta* meta, hipStream_t s) {
+  const uint32_t ntiles = (uint32_t)((len + QH_TILE_BYTES - 1) / QH_TILE_BYTES);
+  if (ntiles) hipLaunchKernelGGL(k_count_newlines, dim3(ntiles), dim3(QH_BLOCK), 0, s, buf, len, tile_counts);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_counts, ntiles, buf, len, rec_cap, meta);
+  if (ntiles)
+    hipLaunchKernelGGL(k_fill_records, dim3(ntiles), dim3(QH_BLOCK), 0, s, buf, len, tile_counts,
+                       reinterpret_cast<uint32_t*>(recs), rec_cap, meta);
+  hipLaunchKernelGGL(k_validate_records, dim3(1024), dim3(QH_BLOCK), 0, s, recs, meta);
+}
+
+// ---------------------------------------------------------------- slot insertion
+
+// hash_with_quality::add on the single-word slot table. Returns false when the
+// reprobe limit is exhausted (caller queues the item for after the doubling).
+__device__ __forceinline__ bool qh_insert(const qh_geom& g, uint64_t* __restrict__ table, uint64_t home,
+                                          uint64_t tag0, uint32_t q, uint32_t* is_new) {
+  const uint64_t wmask = qh_low_mask(g.wbits);
+  const uint64_t base = home & ~wmask;
+  const uint64_t fresh = q ? 3u : 2u;  // nval of a new entry (mer_database.hpp:105-110 from 0)
+  for (uint32_t i = 0; i <= (uint32_t)g.max_reprobe; ++i) {
+    unsigned long long* slot = reinterpret_cast<unsigned long long*>(table + (base | ((home + i) & wmask)));
+    const uint64_t want = tag0 | (i + 1);
+    uint64_t old = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+      if (old == 0) {
+        const uint64_t prev = atomicCAS(slot, 0ull, (unsigned long long)((want << g.vbits) | fresh));
+        if (prev == 0) { *is_new = 1; return true; }
+        old = prev;
+      }
+      if ((old >> g.vbits) != want) break;  // another key lives here: next probe
+      uint64_t nv;
+      if (!qh_update_val(old & g.vmask, q, g.max_val, &nv)) return true;
+      const uint64_t nw = (old & ~g.vmask) | nv;
+      const uint64_t prev = atomicCAS(slot, (unsigned long long)old, (unsigned long long)nw);
+      if (prev == old) return true;
+      old = prev;
+    }
+  }
+  return false;
+}
+
+__device__ __forceinline__ void qh_overflow(qh_meta* __restrict__ meta, uint64_t* __restrict__ ovf,
+                                            uint64_t ovf_cap, uint64_t item) {
+  const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(&meta->ovf_count), 1ull);
+  if (at < ovf_cap) ovf[at] = item;
+  else meta->ovf_lost = 1;
+}
+
+// 32 plane bits -> even bit positions of a 64-bit word
+__device__ __forceinline__ uint64_t spread32(uint32_t v) {
+  uint64_t x = v;
+  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x | (x << 2)) & 0x3333333333333333ull;
+  x = (x | (x << 1)) & 0x5555555555555555ull;
+  return x;
+}
+
+// Wave-parallel form of create_database.cc:64-92 for one 64-base column block of
+// one read. Each lane owns one base; the wave's four ballots are the bit planes
+// (valid, high-quality, code bit 0, code bit 1) of 64 consecutive positions, and
+// the k-mer ending at a lane's base is the k-bit window ending at its bit of the
+// (previous block : this block) plane pair. "low_len >= k" is "valid window all
+// ones", "high_len >= k" is "hq window all ones": the registers m/rm of the
+// scalar loop never need clearing because only complete windows are emitted.
+struct qh_planes { uint64_t v, h, l0, l1; };
+
+__device__ __forceinline__ uint64_t window_top(uint64_t cur, uint64_t prev, int lane) {
+  // bit 63 = this lane's position, bit 63-i = i positions earlier
+  return (cur << (63 - lane)) | ((prev >> lane) >> 1);
+}
+
+__device__ __forceinline__ bool qh_lane_kmer(const qh_planes& cur, const qh_planes& prev, int lane, int k,
+                                             uint64_t* key, uint32_t* hq) {
+  const uint64_t kones = (1ull << k) - 1;
+  const int drop = 64 - k;
+  if ((window_top(cur.v, prev.v, lane) >> drop) != kones) return false;
+  *hq = (window_top(cur.h, prev.h, lane) >> drop) == kones;
+  const uint64_t x0 = window_top(cur.l0, prev.l0, lane), x1 = window_top(cur.l1, prev.l1, lane);
+  // forward mer: base i (i = 0 newest) is window bit 63-i -> bit-reverse
+  const uint32_t m0 = (uint32_t)(__builtin_bitreverse64(x0) & kones);
+  const uint32_t m1 = (uint32_t)(__builtin_bitreverse64(x1) & kones);
+  // reverse complement: base i = 3 - (forward base k-1-i) -> complemented window, oldest base lowest
+  const uint32_t r0 = (uint32_t)((~x0) >> drop), r1 = (uint32_t)((~x1) >> drop);
+  const uint64_t m = spread32(m0) | (spread32(m1) << 1);
+  const uint64_t rm = spread32(r0) | (spread32(r1) << 1);
+  *key = m < rm ? m : rm;  // create_database.cc:86
+  return true;
+}
+
+__device__ __forceinline__ qh_planes qh_load_planes(const uint8_t* __restrict__ buf, uint32_t s0, uint32_t q0,
+                                                    uint32_t len, uint32_t c0, int lane, int min_qual) {
+  const uint32_t j = c0 + lane;
+  const bool inb = j < len;
+  const unsigned b = inb ? buf[(size_t)s0 + j] : 0u;
+  const int ql = inb ? (int)(int8_t)buf[(size_t)q0 + j] : -128;
+  const int code = qh_code(b);
+  const bool valid = code >= 0;
+  qh_planes p;
+  p.v = __ballot(valid);
+  p.h = __ballot(valid && ql >= (int)(int8_t)min_qual);  // signed char compare, create_database.cc:81
+  p.l0 = __ballot(valid && (code & 1));
+  p.l1 = __ballot(valid && (code & 2));
+  return p;
+}
+
+// One wave per read (grid-stride). Direct build: every emitted k-mer is inserted
+// with global 64-bit CAS.
+__global__ __launch_bounds__(QH_BLOCK) void k_build_direct(const uint8_t* __restrict__ buf,
+                                                           const uint4* __restrict__ recs,
+                                                           qh_meta* __restrict__ meta, const qh_geom g,
+                                                           uint64_t* __restrict__ table,
+                                                           uint64_t* __restrict__ ovf, uint64_t ovf_cap) {
+  if (meta->format_err) return;  // chunk rejected as a whole: nothing may be inserted
+  const uint32_t nrec = meta->nrec;
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  uint32_t n_inst = 0, n_hq = 0, n_new = 0, n_foreign = 0;
+  for (uint32_t r = __builtin_amdgcn_readfirstlane(wave0); r < nrec; r += nwaves) {
+    const uint4 rc = recs[r];
+    const uint32_t s0 = rc.x, len = rc.y, q0 = rc.z;
+    qh_planes prev = {0, 0, 0, 0};
+    for (uint32_t c0 = 0; c0 < len; c0 += 64) {
+      const qh_planes cur = qh_load_planes(buf, s0, q0, len, c0, lane, g.min_qual);
+      uint64_t key;
+      uint32_t q;
+      if (qh_lane_kmer(cur, prev, lane, g.k, &key, &q)) {
+        const qh_pos p = qh_locate(g, key);
+        if (p.shard != (uint32_t)g.shard_id) {
+          ++n_foreign;
+        } else {
+          ++n_inst;
+          n_hq += q;
+          uint32_t is_new = 0;
+          if (!qh_insert(g, table, p.home, p.tag0, q, &is_new)) qh_overflow(meta, ovf, ovf_cap, (key << 1) | q);
+          n_new += is_new;
+        }
+      }
+      prev = cur;
+    }
+  }
+  n_inst = wave_sum_u32(n_inst); n_hq = wave_sum_u32(n_hq);
+  n_new = wave_sum_u32(n_new); n_foreign = wave_sum_u32(n_foreign);
+  if (lane == 0) {
+    if (n_inst) atomicAdd(reinterpret_cast<unsigned long long*>(&meta->instances), (unsigned long long)n_inst);
+    if (n_hq) atomicAdd(reinterpret_cast<unsigned long long*>(&meta->hq_instances), (unsigned long long)n_hq);
+    if (n_new) atomicAdd(reinterpret_cast<unsigned long long*>(&meta->new_keys), (unsigned long long)n_new);
+    if (n_foreign) atomicAdd(reinterpret_cast<unsigned long long*>(&meta->foreign), (unsigned long long)n_foreign);
+  }
+}
+
+void qh_launch_build_direct(const uint8_t* buf, const uint4* recs, qh_meta* meta, const qh_geom& g,
+                            uint64_t* table, uint64_t* ovf, uint64_t ovf_cap, hipStream_t s) {
+  hipLaunchKernelGGL(k_build_direct, dim3(2048), dim3(QH_BLOCK), 0, s, buf, recs, meta, g, table, ovf, ovf_cap);
+}
+
+// packed items (mer << 1 | q): one lane per item
+__global__ __launch_bounds__(QH_BLOCK) void k_insert_items(const uint64_t* __restrict__ items, uint64_t n,
+                                                           qh_meta* __restrict__ meta, const qh_geom g,
+                                                           uint64_t* __restrict__ table,
+                                                           uint64_t* __restrict__ ovf, uint64_t ovf_cap,
+                                                           int count_instances) {
+  const int lane = threadIdx.x & 63;
+  uint32_t n_inst = 0, n_hq = 0, n_new = 0, n_foreign = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t it = items[i];
+    const uint64_t key = (it >> 1) & g.kmask;
+    const uint32_t q = (uint32_t)(it & 1);
+    const qh_pos p = qh_locate(g, key);
+    if (p.shard != (uint32_t)g.shard_id) { ++n_foreign; continue; }
+    ++n_inst; n_hq += q;
+    uint32_t is_new = 0;
+    if (!qh_insert(g, table, p.home, p.tag0, q, &is_new)) qh_overflow(meta, ovf, ovf_cap, it);
+    n_new += is_new;
+  }
+  n_inst = wave_sum_u32(n_inst); n_hq = wave_sum_u32(n_hq);
+  n_new = wave_sum_u32(n_new); n_foreign = wave_sum_u32(n_foreign);
+  if (lane == 0) {
+    if (count_instances) {
+      if (n_inst) atomicAdd(reinterpret_cast<unsigned long long*>(&meta->instances), (unsigned long long)n_inst);
+      if (n_hq) atomicAdd(reinterpret_cast<unsigned long long*>(&meta->hq_instances), (unsigned long long)n_hq);
+      if (n_foreign) atomicAdd(reinterpret_cast<unsigned long long*>(&meta->foreign), (unsigned long long)n_foreign);
+    }
+    if (n_new) atomicAdd(reinterpret_cast<unsigned long long*>(&meta->new_keys), (unsigned long long)n_new);
+  }
+}
+
+static inline unsigned grid_for(uint64_t n, unsigned block, unsigned max_blocks) {
+  uint64_t b = (n + block - 1) / block;
+  if (b < 1) b = 1;
+  return (unsigned)(b > max_blocks ? max_blocks : b);
+}
+
+void qh_launch_insert_items(const uint64_t* items, uint64_t n, int count_instances, qh_meta* meta,
+                            const qh_geom& g, uint64_t* table, uint64_t* ovf, uint64_t ovf_cap,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(k_insert_items, dim3(grid_for(n, QH_BLOCK, 4096)), dim3(QH_BLOCK), 0, s, items, n, meta, g,
+                     table, ovf, ovf_cap, count_instances);
+}
+
+// old slot -> new table; the value field is carried over (mer_database.hpp:170-176)
+__global__ __launch_bounds__(QH_BLOCK) void k_rehash(const uint64_t* __restrict__ old_table, const qh_geom og,
+                                                     uint64_t* __restrict__ new_table, const qh_geom ng,
+                                                     qh_meta* __restrict__ meta) {
+  const uint64_t n = qh_table_slots(og);
+  const uint64_t wmask = qh_low_mask(ng.wbits);
+  for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t s = old_table[idx];
+    if (!s) continue;
+    const uint64_t key = qh_slot_key(og, s, idx);
+    const uint64_t val = s & og.vmask;
+    const qh_pos p = qh_locate(ng, key);
+    const uint64_t base = p.home & ~wmask;
+    bool done = false;
+    for (uint32_t i = 0; i <= (uint32_t)ng.max_reprobe && !done; ++i) {
+      unsigned long long* slot = reinterpret_cast<unsigned long long*>(new_table + (base | ((p.home + i) & wmask)));
+      const uint64_t nw = ((p.tag0 | (i + 1)) << ng.vbits) | val;
+      done = atomicCAS(slot, 0ull, (unsigned long long)nw) == 0;  // keys of the old table are distinct
+    }
+    if (!done) meta->rehash_fail = 1;
+  }
+}
+
+void qh_launch_rehash(const uint64_t* old_table, const qh_geom& og, uint64_t* new_table, const qh_geom& ng,
+                      qh_meta* meta, hipStream_t s) {
+  hipLaunchKernelGGL(k_rehash, dim3(grid_for(qh_table_slots(og), QH_BLOCK, 8192)), dim3(QH_BLOCK), 0, s, old_table,
+                     og, new_table, ng, meta);
+}
+
+// Multi-GPU front end: the chunk's items bucketed by owner shard. One atomic per
+// (wave, shard, 64-base block) reserves the output range.
+__global__ __launch_bounds__(QH_BLOCK) void k_extract_partitioned(const uint8_t* __restrict__ buf,
+                                                                  const uint4* __restrict__ recs,
+                                                                  qh_meta* __restrict__ meta, const qh_geom g,
+                                                                  uint64_t* __restrict__ out,
+                                                                  uint64_t cap_per_shard,
+                                                                  unsigned long long* __restrict__ counts) {
+  if (meta->format_err) return;
+  const uint32_t nrec = meta->nrec;
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t nshards = 1u << g.shard_bits;
+  uint32_t n_inst = 0, n_hq = 0;
+  for (uint32_t r = __builtin_amdgcn_readfirstlane(wave0); r < nrec; r += nwaves) {
+    const uint4 rc = recs[r];
+    const uint32_t s0 = rc.x, len = rc.y, q0 = rc.z;
+    qh_planes prev = {0, 0, 0, 0};
+    for (uint32_t c0 = 0; c0 < len; c0 += 64) {
+      const qh_planes cur = qh_load_planes(buf, s0, q0, len, c0, lane, g.min_qual);
+      uint64_t key = 0;
+      uint32_t q = 0;
+      const bool emit = qh_lane_kmer(cur, prev, lane, g.k, &key, &q);
+      const uint32_t shard = emit ? qh_locate(g, key).shard : 0xFFFFFFFFu;
+      n_inst += emit; n_hq += emit ? q : 0;
+      for (uint32_t s = 0; s < nshards; ++s) {
+        const uint64_t mask = __ballot(shard == s);
+        if (!mask) continue;
+        unsigned long long base = 0;
+        if (lane == (int)(__ffsll((unsigned long long)mask) - 1))
+          base = atomicAdd(&counts[s], (unsigned long long)__popcll(mask));
+        base = __shfl(base, __ffsll((unsigned long long)mask) - 1, 64);
+        if (shard == s) {
+          const unsigned long long at = base + lanes_below(mask);
+          if (at < cap_per_shard) out[(uint64_t)s * cap_per_shard + at] = (key << 1) | q;
+          else meta->ovf_lost = 1;
+        }
+      }
+      prev = cur;
+    }
+  }
+  n_inst = wave_sum_u32(n_inst); n_hq = wave_sum_u32(n_hq);
+  if (lane == 0 && n_inst) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(&meta->instances), (unsigned long long)n_inst);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&meta->hq_instances), (unsigned long long)n_hq);
+  }
+}
+
+void qh_launch_extract_partitioned(const uint8_t* buf, const uint4* recs, qh_meta* meta, const qh_geom& g,
+                                   uint64_t* out, uint64_t cap_per_shard, unsigned long long* counts,
+                                   hipStream_t s) {
+  hipLaunchKernelGGL(k_extract_partitioned, dim3(2048), dim3(QH_BLOCK), 0, s, buf, recs, meta, g, out,
+                     cap_per_shard, counts);
+}
+
+// ---------------------------------------------------------------------- read side
+
+// database_query::operator[] (mer_database.hpp:284-293)
+__device__ __forceinline__ uint64_t qh_lookup(const qh_geom& g, const uint64_t* __restrict__ table, uint64_t key) {
+  const qh_pos p = qh_locate(g, key);
+  if (p.shard != (uint32_t)g.shard_id) return 0;
+  const uint64_t wmask = qh_low_mask(g.wbits);
+  const uint64_t base = p.home & ~wmask;
+  for (uint32_t i = 0; i <= (uint32_t)g.max_reprobe; ++i) {
+    const uint64_t s = table[base | ((p.home + i) & wmask)];
+    if (s == 0) return 0;
+    if ((s >> g.vbits) == (p.tag0 | (i + 1))) return s & g.vmask;
+  }
+  return 0;
+}
+
+__global__ __launch_bounds__(QH_BLOCK) void k_lookup(const uint64_t* __restrict__ table, const qh_geom g,
+                                                     const uint64_t* __restrict__ mers, uint64_t n,
+                                                     uint64_t* __restrict__ out, int get_val) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t m = mers[i];
+    uint64_t v = (m & ~g.kmask) ? 0 : qh_lookup(g, table, m);
+    if (get_val) v = (v & 1) ? v >> 1 : 0;  // mer_database.hpp:296-299
+    out[i] = v;
+  }
+}
+
+void qh_launch_lookup(const uint64_t* table, const qh_geom& g, const uint64_t* mers, uint64_t n, uint64_t* out,
+                      int get_val, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_lookup, dim3(grid_for(n, QH_BLOCK, 8192)), dim3(QH_BLOCK), 0, s, table, g, mers, n, out, get_val);
+}
+
+// get_best_alternatives (mer_database.hpp:302-329): 4 lanes per mer, one per
+// alternative base; lane 0 of each quad folds the four (count, hq) pairs in
+// code order exactly like the upstream loop.
+__global__ __launch_bounds__(QH_BLOCK) void k_best_alternatives(const uint64_t* __restrict__ table, const qh_geom g,
+                                                                const uint64_t* __restrict__ fmers,
+                                                                const uint8_t* __restrict__ backward, uint64_t n,
+                                                                uint64_t* __restrict__ counts,
+                                                                int32_t* __restrict__ ucode,
+                                                                int32_t* __restrict__ level,
+                                                                int32_t* __restrict__ nkept) {
+  const uint64_t total = (n * 4 + blockDim.x - 1) / blockDim.x * blockDim.x;  // keep quads whole
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t i = t >> 2;
+    const uint32_t alt = (uint32_t)(t & 3);
+    uint64_t v = 0;
+    if (i < n) {
+      const unsigned sh = backward[i] ? 2u * (g.k - 1) : 0u;  // kmer.hpp:47-50,101-103
+      const uint64_t m = ((fmers[i] & g.kmask) & ~(3ull << sh)) | ((uint64_t)alt << sh);
+      v = qh_lookup(g, table, qh_canonical(m, g.k));
+    }
+    const int lane = threadIdx.x & 63, q0 = lane & ~3;
+    uint64_t vv[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) vv[a] = __shfl(v, q0 + a, 64);
+    if (alt == 0 && i < n) {
+      uint64_t c[4] = {0, 0, 0, 0};
+      int cnt = 0, lvl = 0, uc = 0;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const uint64_t first = vv[a] >> 1;
+        const int second = (int)(vv[a] & 1);
+        if (first > 0 && second >= lvl) {
+          if (second > lvl && cnt > 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (j < a) c[j] = 0;
+            cnt = 0;
+          }
+          c[a] = first; uc = a; lvl = second; ++cnt;
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) counts[i * 4 + a] = c[a];
+      ucode[i] = uc; level[i] = lvl; nkept[i] = cnt;
+    }
+  }
+}
+
+void qh_launch_best_alternatives(const uint64_t* table, const qh_geom& g, const uint64_t* fmers,
+                                 const uint8_t* backward, uint64_t n, uint64_t* counts, int32_t* ucode,
+                                 int32_t* level, int32_t* nkept, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_best_alternatives, dim3(grid_for(n * 4, QH_BLOCK, 8192)), dim3(QH_BLOCK), 0, s, table, g,
+                     fmers, backward, n, counts, ucode, level, nkept);
+}
+
+// error_correct_reads.cc:650-659: distinct += (v&1)&&(v>=2); total += v>>1
+__global__ __launch_bounds__(QH_BLOCK) void k_stats(const uint64_t* __restrict__ table, const qh_geom g,
+                                                    qh_meta* __restrict__ meta) {
+  const uint64_t n = qh_table_slots(g);
+  unsigned long long d = 0, t = 0;
+  for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t v = table[idx] & g.vmask;
+    if ((v & 1) && v >= 2) { d += 1; t += v >> 1; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { d += __shfl_xor(d, o, 64); t += __shfl_xor(t, o, 64); }
+  if ((threadIdx.x & 63) == 0 && d) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(&meta->stat_distinct), d);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&meta->stat_total), t);
+  }
+}
+
+void qh_launch_stats(const uint64_t* table, const qh_geom& g, qh_meta* meta, hipStream_t s) {
+  hipLaunchKernelGGL(k_stats, dim3(grid_for(qh_table_slots(g), QH_BLOCK, 4096)), dim3(QH_BLOCK), 0, s, table, g, meta);
+}
+
+// histo_mer_database.cc:13-21
+__global__ __launch_bounds__(QH_BLOCK) void k_histo(const uint64_t* __restrict__ table, const qh_geom g,
+                                                    unsigned long long* __restrict__ histo) {
+  __shared__ uint32_t h[1001 * 2];
+  for (int i = threadIdx.x; i < 1001 * 2; i += blockDim.x) h[i] = 0;
+  __syncthreads();
+  const uint64_t n = qh_table_slots(g);
+  for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t s = table[idx];
+    if (!s) continue;
+    const uint64_t v = s & g.vmask;
+    uint64_t c = v >> 1;
+    if (c > 1000) c = 1000;
+    atomicAdd(&h[c * 2 + (v & 1)], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 1001 * 2; i += blockDim.x)
+    if (h[i]) atomicAdd(&histo[i], (unsigned long long)h[i]);
+}
+
+void qh_launch_histo(const uint64_t* table, const qh_geom& g, unsigned long long* histo, hipStream_t s) {
+  // each block's 32-bit LDS bins see at most slots/blocks entries
+  hipLaunchKernelGGL(k_histo, dim3(grid_for(qh_table_slots(g), QH_BLOCK, 2048)), dim3(QH_BLOCK), 0, s, table, g, histo);
+}
+
+// database_query iteration (mer_database.hpp:331-361) as a compacting export
+__global__ __launch_bounds__(QH_BLOCK) void k_dump(const uint64_t* __restrict__ table, const qh_geom g,
+                                                   uint64_t* __restrict__ mers, uint64_t* __restrict__ vals,
+                                                   uint64_t cap, qh_meta* __restrict__ meta) {
+  const uint64_t n = qh_table_slots(g);
+  const int lane = threadIdx.x & 63;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t rounds = (n + stride - 1) / stride;
+  for (uint64_t rd = 0; rd < rounds; ++rd) {
+    const uint64_t idx = rd * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t s = idx < n ? table[idx] : 0;
+    const uint64_t mask = __ballot(s != 0);
+    if (!mask) continue;
+    unsigned long long base = 0;
+    const int leader = __ffsll((unsigned long long)mask) - 1;
+    if (lane == leader)
+      base = atomicAdd(reinterpret_cast<unsigned long long*>(&meta->dump_count), (unsigned long long)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (s) {
+      const unsigned long long at = base + lanes_below(mask);
+      if (at < cap) { mers[at] = qh_slot_key(g, s, idx); vals[at] = s & g.vmask; }
+    }
+  }
+}
+
+void qh_launch_dump(const uint64_t* table, const qh_geom& g, uint64_t* mers, uint64_t* vals, uint64_t cap,
+                    qh_meta* meta, hipStream_t s) {
+  hipLaunchKernelGGL(k_dump, dim3(grid_for(qh_table_slots(g), QH_BLOCK, 4096)), dim3(QH_BLOCK), 0, s, table, g, mers,
+                     vals, cap, meta);
+}
+
+// --------------------------------------------------------- roofline microbenchmarks
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+
+// mode 0: one 64-bit atomicCAS per update at a uniformly random slot
+// mode 1: one 8-byte load per update
+// mode 2: relaxed load followed by a dependent CAS (the insert path's shape)
+__global__ __launch_bounds__(QH_BLOCK) void k_random_access(uint64_t* __restrict__ table, int lsize, uint64_t n,
+                                                            int mode, uint64_t seed,
+                                                            unsigned long long* __restrict__ sink) {
+  const uint64_t mask = (1ull << lsize) - 1;
+  unsigned long long acc = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t r = mix64(seed + i * 0x9e3779b97f4a7c15ull);
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(table + (r & mask));
+    if (mode == 0) {
+      acc += atomicCAS(p, 0ull, (unsigned long long)(r | 1));
+    } else if (mode == 1) {
+      acc += *p;
+    } else {
+      const unsigned long long old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      acc += atomicCAS(p, old, old + 2);
+    }
+  }
+  if (acc == 0x123456789abcdefull) *sink = acc;  // keep the loads alive
+}
+
+void qh_launch_random_access(uint64_t* table, int lsize, uint64_t n, int mode, uint64_t seed,
+                             unsigned long long* sink, hipStream_t s) {
+  hipLaunchKernelGGL(k_random_access, dim3(8192), dim3(QH_BLOCK), 0, s, table, lsize, n, mode, seed, sink);
+}

@@ -1,0 +1,291 @@
+// qh_query.hip -- read side of the C ABI: database_query (src/mer_database.hpp:251-362)
+// as batched GPU lookups over the table resident in HBM, plus the whole-table
+// reductions its callers run (src/error_correct_reads.cc:650-659,
+// src/histo_mer_database.cc:13-21) and the roofline microbenchmark.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <unistd.h>
+#include <fcntl.h>
+#include <errno.h>
+#include <sys/stat.h>
+#include <vector>
+
+#include "qh_internal.h"
+#include "qh_dbfile.h"
+
+int qh_ensure_device(void** p, size_t* cap, size_t need, const char* what) {
+  if (*cap >= need && *p) return QH_OK;
+  if (*p) { hipError_t e = hipFree(*p); (void)e; *p = nullptr; *cap = 0; }
+  const size_t want = need + need / 8 + 256;
+  hipError_t e = hipMalloc(p, want);
+  if (e != hipSuccess) { *p = nullptr; return qh_fail(QH_ENOMEM, "hipMalloc of %zu bytes for %s failed: %s", want, what, hipGetErrorString(e)); }
+  *cap = want;
+  return QH_OK;
+}
+
+static int query_init_common(qh_query* q) {
+  QH_HIP(hipSetDevice(q->device));
+  QH_HIP(hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking));
+  QH_HIP(hipMalloc((void**)&q->d_meta, sizeof(qh_meta)));
+  QH_HIP(hipHostMalloc((void**)&q->h_meta, sizeof(qh_meta), hipHostMallocDefault));
+  return QH_OK;
+}
+
+int qh_query_from_table(int device, uint64_t* table, const qh_geom& g, qh_query** out) {
+  qh_query* q = new qh_query();
+  q->device = device; q->g = g; q->table = table; q->owns_table = false;
+  int rc = query_init_common(q);
+  if (rc) { qh_query_close(q); return rc; }
+  *out = q;
+  return QH_OK;
+}
+
+extern "C" int qh_query_open(qh_query** out, const char* path, int device) {
+  if (!out || !path) return qh_fail(QH_EBADARG, "null argument");
+  *out = nullptr;
+  qh_file_header fh;
+  std::string err;
+  if (!qh_header_read_file(path, fh, err)) return qh_fail(QH_EIO, "%s", err.c_str());
+  qh_geom g;
+  if (!qh_geom_from_header(fh, g, err)) return qh_fail(QH_EFORMAT, "%s for file '%s'", err.c_str(), path);
+  int fd = open(path, O_RDONLY);
+  if (fd < 0) return qh_fail(QH_EIO, "Can't open '%s' for reading", path);
+  struct stat sb;
+  if (fstat(fd, &sb) != 0 || (uint64_t)sb.st_size < fh.offset + fh.key_bytes + fh.value_bytes) {
+    close(fd);
+    return qh_fail(QH_EIO, "file '%s' is shorter than its header says", path);
+  }
+  qh_query* q = new qh_query();
+  q->device = device; q->g = g;
+  int rc = query_init_common(q);
+  if (rc) { close(fd); qh_query_close(q); return rc; }
+  hipError_t e = hipMalloc((void**)&q->table, fh.key_bytes);
+  if (e != hipSuccess) { close(fd); qh_query_close(q); return qh_fail(QH_ENOMEM, "cannot allocate %llu bytes of HBM for the table: %s", (unsigned long long)fh.key_bytes, hipGetErrorString(e)); }
+  // stream the keys image into HBM through a pinned staging buffer
+  const size_t piece = (size_t)64 << 20;
+  void* stage = nullptr;
+  e = hipHostMalloc(&stage, piece, hipHostMallocDefault);
+  if (e != hipSuccess) { close(fd); qh_query_close(q); return qh_fail(QH_ENOMEM, "cannot allocate the staging buffer"); }
+  rc = QH_OK;
+  for (uint64_t at = 0; at < fh.key_bytes && rc == QH_OK; at += piece) {
+    const size_t n = fh.key_bytes - at < piece ? (size_t)(fh.key_bytes - at) : piece;
+    size_t got = 0;
+    while (got < n) {
+      ssize_t r = pread(fd, (char*)stage + got, n - got, (off_t)(fh.offset + at + got));
+      if (r < 0 && errno == EINTR) continue;
+      if (r <= 0) { rc = qh_fail(QH_EIO, "Failed to read in file '%s'", path); break; }
+      got += (size_t)r;
+    }
+    if (rc) break;
+    e = hipMemcpyAsync((char*)q->table + at, stage, n, hipMemcpyHostToDevice, q->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(q->stream);
+    if (e != hipSuccess) rc = qh_fail(QH_EHIP, "copying the table to the device failed: %s", hipGetErrorString(e));
+  }
+  e = hipHostFree(stage); (void)e;
+  close(fd);
+  if (rc) { qh_query_close(q); return rc; }
+  *out = q;
+  return QH_OK;
+}
+
+extern "C" int qh_db_header_info(const char* path, qh_db_info* info) {
+  if (!path || !info) return qh_fail(QH_EBADARG, "null argument");
+  qh_file_header fh;
+  std::string err;
+  if (!qh_header_read_file(path, fh, err)) return qh_fail(QH_EIO, "%s", err.c_str());
+  memset(info, 0, sizeof *info);
+  info->size = fh.size; info->key_len = fh.key_len; info->val_len = fh.val_len;
+  info->max_reprobe = fh.max_reprobe; info->bits = fh.bits;
+  info->key_bytes = fh.key_bytes; info->value_bytes = fh.value_bytes; info->offset = fh.offset;
+  info->shard_bits = fh.shard_bits; info->window_bits = fh.window_bits;
+  snprintf(info->format, sizeof info->format, "%s", fh.format.c_str());
+  if (fh.format != "binary/quorum_db") return qh_fail(QH_EFORMAT, "Wrong type '%s' for file '%s'", fh.format.c_str(), path);
+  return QH_OK;
+}
+
+extern "C" void qh_query_close(qh_query* q) {
+  if (!q) return;
+  hipError_t e = hipSetDevice(q->device); (void)e;
+  if (q->stream) { e = hipStreamSynchronize(q->stream); (void)e; }
+  void* ptrs[] = {q->owns_table ? (void*)q->table : nullptr, q->d_meta, q->d_in, q->d_in2, q->d_out};
+  for (void* p : ptrs) if (p) { e = hipFree(p); (void)e; }
+  if (q->h_meta) { e = hipHostFree(q->h_meta); (void)e; }
+  if (q->stream) { e = hipStreamDestroy(q->stream); (void)e; }
+  delete q;
+}
+
+extern "C" int qh_query_info(const qh_query* q, int* k, int* bits, uint64_t* size) {
+  if (!q) return qh_fail(QH_EBADARG, "null handle");
+  if (k) *k = q->g.k;
+  if (bits) *bits = q->g.bits;
+  if (size) *size = qh_table_slots(q->g);
+  return QH_OK;
+}
+
+extern "C" int qh_query_batch_device(qh_query* q, const uint64_t* dev_mers, size_t n, uint64_t* dev_out, void* hip_stream) {
+  if (!q) return qh_fail(QH_EBADARG, "null handle");
+  if (n == 0) return QH_OK;
+  if (!dev_mers || !dev_out) return qh_fail(QH_EBADARG, "null buffer");
+  QH_HIP(hipSetDevice(q->device));
+  qh_launch_lookup(q->table, q->g, dev_mers, n, dev_out, 0, hip_stream ? (hipStream_t)hip_stream : q->stream);
+  QH_HIP(hipGetLastError());
+  return QH_OK;
+}
+
+static int lookup_host(qh_query* q, const uint64_t* mers, size_t n, uint64_t* out, int get_val) {
+  if (!q) return qh_fail(QH_EBADARG, "null handle");
+  if (n == 0) return QH_OK;
+  if (!mers || !out) return qh_fail(QH_EBADARG, "null buffer");
+  std::lock_guard<std::mutex> lock(q->mu);
+  QH_HIP(hipSetDevice(q->device));
+  int rc;
+  if ((rc = qh_ensure_device(&q->d_in, &q->in_cap, n * 8, "query keys"))) return rc;
+  if ((rc = qh_ensure_device(&q->d_out, &q->out_cap, n * 8, "query results"))) return rc;
+  QH_HIP(hipMemcpyAsync(q->d_in, mers, n * 8, hipMemcpyHostToDevice, q->stream));
+  qh_launch_lookup(q->table, q->g, (const uint64_t*)q->d_in, n, (uint64_t*)q->d_out, get_val, q->stream);
+  QH_HIP(hipGetLastError());
+  QH_HIP(hipMemcpyAsync(out, q->d_out, n * 8, hipMemcpyDeviceToHost, q->stream));
+  QH_HIP(hipStreamSynchronize(q->stream));
+  return QH_OK;
+}
+
+extern "C" int qh_query_batch(qh_query* q, const uint64_t* mers, size_t n, uint64_t* out) {
+  return lookup_host(q, mers, n, out, 0);
+}
+
+extern "C" int qh_query_get_val_batch(qh_query* q, const uint64_t* mers, size_t n, uint64_t* out) {
+  return lookup_host(q, mers, n, out, 1);
+}
+
+extern "C" int qh_query_best_alternatives_batch(qh_query* q, const uint64_t* fmers, const uint8_t* backward, size_t n,
+                                                uint64_t* counts, int32_t* ucode, int32_t* level, int32_t* nkept) {
+  if (!q) return qh_fail(QH_EBADARG, "null handle");
+  if (n == 0) return QH_OK;
+  if (!fmers || !backward || !counts || !ucode || !level || !nkept) return qh_fail(QH_EBADARG, "null buffer");
+  std::lock_guard<std::mutex> lock(q->mu);
+  QH_HIP(hipSetDevice(q->device));
+  int rc;
+  // d_in: fmers; d_in2: backward flags; d_out: counts[n][4] then ucode, level, nkept
+  if ((rc = qh_ensure_device(&q->d_in, &q->in_cap, n * 8, "query keys"))) return rc;
+  if ((rc = qh_ensure_device(&q->d_in2, &q->in2_cap, n, "direction flags"))) return rc;
+  if ((rc = qh_ensure_device(&q->d_out, &q->out_cap, n * (32 + 12), "query results"))) return rc;
+  uint64_t* d_counts = (uint64_t*)q->d_out;
+  int32_t* d_ucode = (int32_t*)(d_counts + n * 4);
+  int32_t* d_level = d_ucode + n;
+  int32_t* d_nkept = d_level + n;
+  QH_HIP(hipMemcpyAsync(q->d_in, fmers, n * 8, hipMemcpyHostToDevice, q->stream));
+  QH_HIP(hipMemcpyAsync(q->d_in2, backward, n, hipMemcpyHostToDevice, q->stream));
+  qh_launch_best_alternatives(q->table, q->g, (const uint64_t*)q->d_in, (const uint8_t*)q->d_in2, n, d_counts, d_ucode,
+                              d_level, d_nkept, q->stream);
+  QH_HIP(hipGetLastError());
+  QH_HIP(hipMemcpyAsync(counts, d_counts, n * 32, hipMemcpyDeviceToHost, q->stream));
+  QH_HIP(hipMemcpyAsync(ucode, d_ucode, n * 4, hipMemcpyDeviceToHost, q->stream));
+  QH_HIP(hipMemcpyAsync(level, d_level, n * 4, hipMemcpyDeviceToHost, q->stream));
+  QH_HIP(hipMemcpyAsync(nkept, d_nkept, n * 4, hipMemcpyDeviceToHost, q->stream));
+  QH_HIP(hipStreamSynchronize(q->stream));
+  return QH_OK;
+}
+
+extern "C" int qh_query_stats(qh_query* q, uint64_t* distinct, uint64_t* total) {
+  if (!q || !distinct || !total) return qh_fail(QH_EBADARG, "null argument");
+  std::lock_guard<std::mutex> lock(q->mu);
+  QH_HIP(hipSetDevice(q->device));
+  QH_HIP(hipMemsetAsync(q->d_meta, 0, sizeof(qh_meta), q->stream));
+  qh_launch_stats(q->table, q->g, q->d_meta, q->stream);
+  QH_HIP(hipGetLastError());
+  QH_HIP(hipMemcpyAsync(q->h_meta, q->d_meta, sizeof(qh_meta), hipMemcpyDeviceToHost, q->stream));
+  QH_HIP(hipStreamSynchronize(q->stream));
+  *distinct = q->h_meta->stat_distinct;
+  *total = q->h_meta->stat_total;
+  return QH_OK;
+}
+
+extern "C" int qh_query_histo(qh_query* q, uint64_t* histo) {
+  if (!q || !histo) return qh_fail(QH_EBADARG, "null argument");
+  std::lock_guard<std::mutex> lock(q->mu);
+  QH_HIP(hipSetDevice(q->device));
+  const size_t bytes = 1001 * 2 * sizeof(uint64_t);
+  int rc;
+  if ((rc = qh_ensure_device(&q->d_out, &q->out_cap, bytes, "histogram"))) return rc;
+  QH_HIP(hipMemsetAsync(q->d_out, 0, bytes, q->stream));
+  qh_launch_histo(q->table, q->g, (unsigned long long*)q->d_out, q->stream);
+  QH_HIP(hipGetLastError());
+  QH_HIP(hipMemcpyAsync(histo, q->d_out, bytes, hipMemcpyDeviceToHost, q->stream));
+  QH_HIP(hipStreamSynchronize(q->stream));
+  return QH_OK;
+}
+
+int qh_table_dump(int device, hipStream_t stream, const uint64_t* table, const qh_geom& g, qh_meta* d_meta, qh_meta* h_meta,
+                  uint64_t* mers, uint64_t* vals, uint64_t cap, uint64_t* n) {
+  QH_HIP(hipSetDevice(device));
+  if (cap && (!mers || !vals)) return qh_fail(QH_EBADARG, "null output");
+  uint64_t* d_mers = nullptr;
+  uint64_t* d_vals = nullptr;
+  if (cap) {
+    QH_HIP(hipMalloc((void**)&d_mers, cap * 8));
+    hipError_t e = hipMalloc((void**)&d_vals, cap * 8);
+    if (e != hipSuccess) { (void)hipFree(d_mers); return qh_fail(QH_ENOMEM, "cannot allocate the dump buffers"); }
+  }
+  hipError_t e = hipMemsetAsync(d_meta, 0, sizeof(qh_meta), stream);
+  if (e == hipSuccess) {
+    qh_launch_dump(table, g, d_mers, d_vals, cap, d_meta, stream);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(h_meta, d_meta, sizeof(qh_meta), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e == hipSuccess) {
+    *n = h_meta->dump_count;
+    const uint64_t m = *n < cap ? *n : cap;
+    if (m) {
+      e = hipMemcpy(mers, d_mers, m * 8, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(vals, d_vals, m * 8, hipMemcpyDeviceToHost);
+    }
+  }
+  if (d_mers) (void)hipFree(d_mers);
+  if (d_vals) (void)hipFree(d_vals);
+  if (e != hipSuccess) return qh_fail(QH_EHIP, "table dump failed: %s", hipGetErrorString(e));
+  return QH_OK;
+}
+
+extern "C" int qh_query_dump(qh_query* q, uint64_t* mers, uint64_t* vals, uint64_t cap, uint64_t* n) {
+  if (!q || !n) return qh_fail(QH_EBADARG, "null argument");
+  std::lock_guard<std::mutex> lock(q->mu);
+  return qh_table_dump(q->device, q->stream, q->table, q->g, q->d_meta, q->h_meta, mers, vals, cap, n);
+}
+
+// --------------------------------------------------------- roofline microbenchmark
+
+extern "C" int qh_bench_random_access(int device, int lsize, uint64_t n_updates, int mode, int iters, double* ms) {
+  if (!ms || lsize < 4 || lsize > 36 || iters < 1 || mode < 0 || mode > 2) return qh_fail(QH_EBADARG, "bad argument");
+  QH_HIP(hipSetDevice(device));
+  uint64_t* table = nullptr;
+  unsigned long long* sink = nullptr;
+  const size_t bytes = (size_t)8 << lsize;
+  QH_HIP(hipMalloc((void**)&table, bytes));
+  hipError_t e = hipMalloc((void**)&sink, 8);
+  hipStream_t s = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  if (e == hipSuccess) e = hipMemsetAsync(table, 0, bytes, s);
+  float total = 0;
+  for (int it = -1; it < iters && e == hipSuccess; ++it) {  // it == -1: warm-up
+    e = hipEventRecord(e0, s);
+    qh_launch_random_access(table, lsize, n_updates, mode, 0x1234u + (uint64_t)(it + 1) * 7919u, sink, s);
+    if (e == hipSuccess) e = hipEventRecord(e1, s);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float t = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
+    if (it >= 0) total += t;
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (s) (void)hipStreamDestroy(s);
+  if (sink) (void)hipFree(sink);
+  (void)hipFree(table);
+  if (e != hipSuccess) return qh_fail(QH_EHIP, "random-access benchmark failed: %s", hipGetErrorString(e));
+  *ms = total / iters;
+  return QH_OK;
+}

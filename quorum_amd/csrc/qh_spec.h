@@ -1,0 +1,158 @@
+// qh_spec.h -- table geometry, k-mer codec and position hash shared by the host
+// code and the gfx950 kernels of libquorum_hip.
+//
+// Upstream semantics this replaces (paths relative to the Quorum tree):
+//   jellyfish::mer_dna codec used at src/create_database.cc:73-86
+//   jellyfish::large_hash::array geometry used at src/mer_database.hpp:78-81
+//   value field "count<<1 | hq" and max_val    src/mer_database.hpp:83,102-111
+//
+// Slot design (one 64-bit word per slot, claimed AND updated by one 64-bit CAS):
+//
+//   63 ............................................................. 0
+//   [ remainder : rbits ][ probe+1 : pbits ][ value = count<<1|hq : vbits ]
+//
+// h   = qh_mix(canonical k-mer)            bijection on 2k-bit integers
+// owner shard = h & (2^shard_bits - 1)     (0 when the table is not sharded; it does
+//                                           not depend on lsize, so a shard can double)
+// local home  = (h >> shard_bits) & (2^lsize - 1)
+// remainder   = h >> gsize                 gsize = lsize + shard_bits, rbits = max(0, 2k - gsize)
+// probing     = linear inside the 2^wbits-slot window that contains the home
+//               slot: idx = (home & ~wmask) | ((home + i) & wmask), i <= max_reprobe
+// A slot is empty iff the whole word is 0 (an occupied slot has probe+1 >= 1).
+// The key of an occupied slot is recovered as
+//   qh_unmix( remainder << gsize | ((window base | (idx - i) & wmask)) << shard_bits | shard ).
+// A table that holds ALL shards back to back (all_shards = 1: the serialised file,
+// a query handle) indexes slot (shard << lsize) | local home.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#include <hip/hip_runtime.h>
+#define QH_HD __host__ __device__ __forceinline__
+#else
+#define QH_HD inline
+#endif
+
+#define QH_WINDOW_BITS 14          // 16384 slots = 128 KiB: one window fits a CU's LDS
+#define QH_MIX_C1 0xff51afd7ed558ccdULL
+#define QH_MIX_C2 0xc4ceb9fe1a85ec53ULL
+#define QH_MIX_C1_INV 0x4f74430c22a54005ULL   // C1 * C1_INV == 1 (mod 2^64)
+#define QH_MIX_C2_INV 0x9cb4b2f8129337dbULL   // C2 * C2_INV == 1 (mod 2^64)
+
+struct qh_geom {
+  int32_t k;            // mer length, 1..31
+  int32_t bits;         // count bits (-b); value field is bits+1 wide
+  int32_t vbits;        // bits + 1
+  int32_t pbits;        // width of the probe+1 field
+  int32_t rbits;        // width of the remainder field
+  int32_t lsize;        // log2(slots in THIS shard)
+  int32_t shard_bits;   // log2(number of shards)
+  int32_t shard_id;     // which shard this table is
+  int32_t wbits;        // log2(probe window) = min(lsize, QH_WINDOW_BITS)
+  int32_t max_reprobe;  // probe offsets 0..max_reprobe are tried
+  int32_t min_qual;     // threshold, compared as signed char
+  int32_t all_shards;   // 1: this table is the concatenation of all 2^shard_bits shards
+  uint64_t kmask;       // 2^(2k) - 1
+  uint64_t vmask;       // 2^vbits - 1
+  uint64_t max_val;     // 2^bits - 1
+};
+
+QH_HD uint64_t qh_low_mask(int n) { return n >= 64 ? ~0ULL : ((1ULL << n) - 1); }
+
+// xorshift / odd-multiply rounds on n = 2k bits; every step is a bijection of
+// [0, 2^n), so the stored remainder + home position determine the key.
+QH_HD uint64_t qh_mix(uint64_t x, int k) {
+  const int n = 2 * k, s = (n + 1) >> 1;
+  const uint64_t m = qh_low_mask(n);
+  x ^= x >> s;
+  x = (x * QH_MIX_C1) & m;
+  x ^= x >> s;
+  x = (x * QH_MIX_C2) & m;
+  x ^= x >> s;
+  return x;
+}
+
+QH_HD uint64_t qh_unmix(uint64_t x, int k) {
+  const int n = 2 * k, s = (n + 1) >> 1;
+  const uint64_t m = qh_low_mask(n);
+  x ^= x >> s;                       // 2s >= n: the xorshift is an involution
+  x = (x * QH_MIX_C2_INV) & m;
+  x ^= x >> s;
+  x = (x * QH_MIX_C1_INV) & m;
+  x ^= x >> s;
+  return x;
+}
+
+// reverse complement of a k-mer in the low 2k bits (A=0,C=1,G=2,T=3: comp = 3-c = ~c)
+QH_HD uint64_t qh_revcomp(uint64_t m, int k) {
+  uint64_t x = ~m;
+  x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+  x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+  x = ((x >> 8) & 0x00FF00FF00FF00FFULL) | ((x & 0x00FF00FF00FF00FFULL) << 8);
+  x = ((x >> 16) & 0x0000FFFF0000FFFFULL) | ((x & 0x0000FFFF0000FFFFULL) << 16);
+  x = (x >> 32) | (x << 32);
+  return x >> (64 - 2 * k);
+}
+
+QH_HD uint64_t qh_canonical(uint64_t m, int k) {
+  const uint64_t r = qh_revcomp(m, k);
+  return m < r ? m : r;
+}
+
+// mer_dna::code: A/a C/c G/g T/t -> 0..3, everything else negative
+QH_HD int qh_code(unsigned c) {
+  const unsigned u = c & 0xDFu;
+  return u == 'A' ? 0 : u == 'C' ? 1 : u == 'G' ? 2 : u == 'T' ? 3 : -1;
+}
+
+struct qh_pos {
+  uint64_t home;   // home slot inside this shard
+  uint64_t tag0;   // remainder << pbits (probe field still 0), NOT shifted by vbits
+  uint32_t shard;  // owner shard of the key
+};
+
+QH_HD uint64_t qh_table_slots(const qh_geom& g) {
+  return 1ull << (g.lsize + (g.all_shards ? g.shard_bits : 0));
+}
+
+QH_HD qh_pos qh_locate(const qh_geom& g, uint64_t key) {
+  const uint64_t h = qh_mix(key, g.k);
+  const int gsize = g.lsize + g.shard_bits;
+  qh_pos p;
+  p.shard = (uint32_t)(h & qh_low_mask(g.shard_bits));
+  p.home = (h >> g.shard_bits) & qh_low_mask(g.lsize);
+  p.tag0 = (gsize >= 64 ? 0 : (h >> gsize)) << g.pbits;
+  if (g.all_shards) {
+    p.home |= (uint64_t)p.shard << g.lsize;
+    p.shard = (uint32_t)g.shard_id;
+  }
+  return p;
+}
+
+QH_HD uint64_t qh_probe_idx(const qh_geom& g, uint64_t home, uint32_t i) {
+  const uint64_t wmask = qh_low_mask(g.wbits);
+  return (home & ~wmask) | ((home + i) & wmask);
+}
+
+// key stored in the occupied slot word `slot` found at index `idx`
+QH_HD uint64_t qh_slot_key(const qh_geom& g, uint64_t slot, uint64_t idx) {
+  const uint64_t wmask = qh_low_mask(g.wbits);
+  const uint64_t f = slot >> g.vbits;
+  const uint32_t i = (uint32_t)(f & qh_low_mask(g.pbits)) - 1;
+  const uint64_t rem = f >> g.pbits;
+  const uint64_t home = (idx & ~wmask) | ((idx - i) & wmask);
+  const int gsize = g.lsize + g.shard_bits;
+  const uint64_t shard = g.all_shards ? home >> g.lsize : (uint64_t)g.shard_id;
+  uint64_t h = ((home & qh_low_mask(g.lsize)) << g.shard_bits) | shard;
+  if (gsize < 64) h |= rem << gsize;
+  return qh_unmix(h & g.kmask, g.k);
+}
+
+// Quorum's update rule (src/mer_database.hpp:104-110) on a value field.
+// Returns true when the field must change and writes the new field to *nv.
+QH_HD bool qh_update_val(uint64_t v, uint32_t q, uint64_t max_val, uint64_t* nv) {
+  if ((v & 1) < q) { *nv = 3; return true; }
+  if ((v >> 1) == max_val || (v & 1) > q) return false;
+  *nv = v + 2;
+  return true;
+}
