@@ -100,9 +100,10 @@ extern "C" int qh_build_create(qh_build** out, int k, int bits, uint64_t size, i
   qh_geom g;
   std::string err;
   // sharded: `size` is the TOTAL table size; every shard gets size / 2^shard_bits
+  if (shard_bits < 0 || shard_bits > 8) return qh_fail(QH_EBADARG, "invalid shard specification");
   uint64_t local = size >> shard_bits;
   if (shard_bits && (local << shard_bits) < size) ++local;
-  if (!qh_make_geom(k, bits, local ? local : 1, min_qual, reprobe_limit, shard_bits, shard_id, -1, g, err))
+  if (!qh_make_geom(k, bits, local, min_qual, reprobe_limit, shard_bits, shard_id, -1, g, err))
     return qh_fail(QH_EBADARG, "%s", err.c_str());
   QH_HIP(hipSetDevice(device));
   qh_build* h = new qh_build();

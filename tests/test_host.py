@@ -1,0 +1,135 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and exports
+every symbol include/quorum_hip.h declares, argument validation happens before any
+GPU call, the CLI rejects what the reference rejects, header parsing works without a
+GPU. No compute calls here (no GPU)."""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+
+import pytest
+
+import quorum_amd
+from quorum_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "quorum_amd", "bin", "quorum_create_database")
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "quorum_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(qh_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(_lib.lib, n), "libquorum_hip.so does not export %s" % n
+    bound = {s[0] for s in _lib.SIGNATURES}
+    assert set(names) <= bound, "python binding misses %s" % (set(names) - bound)
+
+
+def test_version_and_error_string():
+    assert b"quorum_hip" in _lib.lib.qh_version()
+    assert isinstance(quorum_amd.last_error(), str)
+
+
+@pytest.mark.parametrize("k,bits,size,msg", [
+    (0, 7, 100, "Mer length"), (32, 7, 100, "Mer length"),
+    (24, 0, 100, "bits should be between 1 and 63"), (24, 64, 100, "bits should be between 1 and 63"),
+    (24, 7, 0, "size"), (31, 40, 1 << 10, "unsupported geometry")])
+def test_create_rejects_bad_geometry_without_gpu(k, bits, size, msg):
+    h = C.c_void_p()
+    st = _lib.lib.qh_build_create(C.byref(h), k, bits, size, 38, 126, 0, 0, 0)
+    assert st == _lib.QH_EBADARG
+    assert msg in quorum_amd.last_error()
+
+
+def test_null_handles_are_rejected():
+    assert _lib.lib.qh_build_sync(None) == _lib.QH_EBADARG
+    assert _lib.lib.qh_build_add_fastq(None, b"x", 1) == _lib.QH_EBADARG
+    assert _lib.lib.qh_query_batch(None, None, 0, None) == _lib.QH_EBADARG
+    _lib.lib.qh_build_destroy(None)
+    _lib.lib.qh_query_close(None)
+
+
+def test_fastq_4line_prefix():
+    f = _lib.lib.qh_fastq_4line_prefix
+    rec = b"@a\nACGT\n+\nIIII\n"
+    assert f(rec * 3, len(rec) * 3, 0) == len(rec) * 3
+    assert f(rec * 3 + b"@b\nAC", len(rec) * 3 + 5, 0) == len(rec) * 3
+    assert f(rec[:-1], len(rec) - 1, 0) == 0
+    assert f(rec[:-1], len(rec) - 1, 1) == len(rec) - 1  # final chunk: last line may lack '\n'
+    assert f(b"", 0, 1) == 0
+
+
+def write_db_file(path, header, payload=b""):
+    j = json.dumps(header).encode()
+    pad = (8 - (9 + len(j)) % 8) % 8
+    with open(path, "wb") as f:
+        f.write(b"%09d" % (len(j) + pad) + j + b"\0" * pad + payload)
+    return 9 + len(j) + pad
+
+
+def test_header_info_parses_reference_style_header(tmp_path):
+    p = str(tmp_path / "db")
+    hdr = {"format": "binary/quorum_db", "size": 1024, "key_len": 48, "val_len": 0, "max_reprobe": 126,
+           "bits": 7, "key_bytes": 8192, "value_bytes": 1024, "cmdline": ["x", "-s", "1k"],
+           "qhip": {"layout": "slot64/1", "hash": "xsmul/1", "window_bits": 10, "probe_bits": 7, "shard_bits": 0}}
+    off = write_db_file(p, hdr, b"\0" * (8192 + 1024))
+    info = _lib.QhDbInfo()
+    assert _lib.lib.qh_db_header_info(p.encode(), C.byref(info)) == _lib.QH_OK
+    assert (info.size, info.key_len, info.bits, info.key_bytes, info.value_bytes) == (1024, 48, 7, 8192, 1024)
+    assert info.offset == off and off % 8 == 0  # test_mer_database.cc:102
+    assert info.format == b"binary/quorum_db"
+
+
+def test_header_info_errors(tmp_path):
+    info = _lib.QhDbInfo()
+    assert _lib.lib.qh_db_header_info(str(tmp_path / "missing").encode(), C.byref(info)) == _lib.QH_EIO
+    assert "Can't open" in quorum_amd.last_error()  # mer_database.hpp:259-260
+    p = str(tmp_path / "garbage")
+    open(p, "wb").write(b"not a database at all")
+    assert _lib.lib.qh_db_header_info(p.encode(), C.byref(info)) == _lib.QH_EIO
+    assert "Can't parse header" in quorum_amd.last_error()  # :262-263
+    p = str(tmp_path / "other")
+    write_db_file(p, {"format": "binary/sorted", "size": 16})
+    assert _lib.lib.qh_db_header_info(p.encode(), C.byref(info)) == _lib.QH_EFORMAT
+    assert "Wrong type" in quorum_amd.last_error()  # :264-265
+
+
+def run_cli(*args):
+    return subprocess.run([CLI] + list(args), capture_output=True, text=True, timeout=60)
+
+
+@pytest.mark.parametrize("args,msg", [
+    (["-m", "24", "-b", "7", "-q", "38", "r.fq"], "[-s, --size=uint64] required switch"),
+    (["-s", "1k", "-b", "7", "-q", "38", "r.fq"], "[-m, --mer=uint32] required switch"),
+    (["-s", "1k", "-m", "24", "-q", "38", "r.fq"], "[-b, --bits=uint32] required switch"),
+    (["-s", "1k", "-m", "24", "-b", "7", "r.fq"], "Either a min-qual-value or min-qual-char must be provided."),
+    (["-s", "1k", "-m", "24", "-b", "7", "-Q", "ab", "r.fq"], "The min-qual-char should be one ASCII character."),
+    (["-s", "1k", "-m", "24", "-b", "7", "-q", "38", "-Q", "a", "r.fq"], "mutually exclusive"),
+    (["-s", "1k", "-m", "24", "-b", "0", "-q", "38", "r.fq"], "The number of bits should be between 1 and 63"),
+    (["-s", "1k", "-m", "24", "-b", "64", "-q", "38", "r.fq"], "The number of bits should be between 1 and 63"),
+    (["-s", "1k", "-m", "24", "-b", "7", "-q", "38"], "Requires at least 1 argument."),
+    (["-s", "12x", "-m", "24", "-b", "7", "-q", "38", "r.fq"], "Invalid conversion"),
+    (["-s", "1k", "-m", "24", "-b", "7", "-q", "38", "-o", "/nonexistent_dir/x", "r.fq"], "Failed to open output file"),
+])
+def test_cli_validation_matches_reference(args, msg, tmp_path):
+    """create_database.cc:104-115 and the yaggo switch rules (create_database_cmdline.yaggo:7-33):
+    message on stderr, exit status 1, before any work is done."""
+    if "-o" not in args:
+        args = ["-o", str(tmp_path / "out")] + args
+    r = run_cli(*args)
+    assert r.returncode == 1
+    assert msg in r.stderr
+
+
+def test_cli_help_lists_reference_switches():
+    r = run_cli("--help")
+    assert r.returncode == 0
+    for sw in ("--size", "--mer", "--bits", "--min-qual-value", "--min-qual-char", "--threads", "--output", "--reprobe"):
+        assert sw in r.stdout
