@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- k-mer insertions/s of the MI355X database build (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one complete database build over one batch of synthetic reads whose FASTQ
+text is already resident in HBM: table clear + FASTQ indexing + k-mer extraction +
+(N>1: all-to-all exchange) + insertion, until every k-mer is visible in the table.
+N=1 workload = BASELINE.json configs[1]: 5 Mbp genome, 2M x 100 bp reads, 1 % errors,
+k=24, -s 50M, -b 7, -q 38 (154 M insertions per step). N>1: weak scaling, the same
+2M reads per GPU drawn from an N x 5 Mbp genome, table -s N x 50M sharded by hash.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+K, BITS, MIN_QUAL, READ_LEN = 24, 7, 38, 100
+GENOME_PER_GPU, READS_PER_GPU, SIZE_PER_GPU = 5_000_000, 2_000_000, 50_000_000
+ALG_BYTES_PER_KMER = 16.0 + 2.0 * READ_LEN / (READ_LEN - K + 1)   # 18.6 B
+HBM_PEAK_GBS = 8000.0                                               # MI355X_MICROARCH.md: 8 TB/s
+
+
+def cpu_baseline(fq, n_reads_total):
+    """The oracle's multithreaded CPU restatement of the reference algorithm, timed on a bounded
+    sample (the first 1M reads). Checker code: never the thing measured as `value`."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    from quorum_amd import synth
+    sample_reads = min(n_reads_total, 1_000_000)
+    nbytes = sample_reads * synth.record_bytes(READ_LEN)
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1)
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    db = po.OracleDB(SIZE_PER_GPU, K, BITS)
+    buf = np.ascontiguousarray(fq[:nbytes])
+    t0 = time.perf_counter()
+    n = db.add_fastq_ptr(buf.ctypes.data, nbytes, MIN_QUAL, threads)
+    dt = time.perf_counter() - t0
+    db.close()
+    return {"value": n / dt, "unit": "k-mers/s", "cores": threads, "kind": "port",
+            "sample": "first %d of the %d reads (%d insertions, %.2f s): oracle/quorum_oracle.c, "
+                      "multithreaded CPU restatement of the reference algorithm (not the upstream binary)"
+                      % (sample_reads, n_reads_total, n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=READS_PER_GPU, help="reads per GPU (default: the named config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from quorum_amd import synth
+    from quorum_amd.dist_build import ShardedBuilder
+
+    genome = synth.make_genome(GENOME_PER_GPU * world, seed=42)
+    fq = synth.make_fastq(genome, args.reads, READ_LEN, err=0.01, n_rate=0.0005, seed=42, first_id=rank * args.reads)
+    chunk = torch.from_numpy(fq).to(dev)           # the FASTQ text, resident in HBM
+    torch.cuda.synchronize()
+
+    b = ShardedBuilder(K, BITS, SIZE_PER_GPU * world, MIN_QUAL, rank, world, local)
+    b.h.enable_timing(True)
+
+    def step():
+        b.reset()
+        b.add_fastq_device(chunk, max_items=args.reads * (READ_LEN - K + 1))
+        b.h.sync()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    st0 = b.h.stats()
+    b.h.enable_timing(True)                         # restart the kernel-time accumulation
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    kms, klaunch = b.h.kernel_time()
+    st = b.h.stats()
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    inst = torch.tensor([float(st["instances"])], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(inst, op=dist.ReduceOp.SUM)
+    dt = float(t.item())
+    per_step = float(inst.item())                   # insertions of ONE step over all ranks (stats are reset each step)
+
+    if rank == 0:
+        kernel_avg_ms = kms / max(1, klaunch)
+        per_launch = st["instances"]                # this rank's insertions per launch of the dominant kernel
+        achieved = per_launch * ALG_BYTES_PER_KMER / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if world == 1 and os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "k-mers/s into HQ-bit hash", "value": per_step * args.steps / dt, "unit": "k-mers/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: synthetic %d Mbp genome, %d x %d bp reads per GPU, 1%% subst errors, "
+                                   "k=%d, -s %dM, -b %d, -q %d; FASTQ resident in HBM; step = clear + index + extract + %sinsert"
+                                   % (GENOME_PER_GPU * world // 1_000_000, args.reads, READ_LEN, K,
+                                      SIZE_PER_GPU * world // 1_000_000, BITS, MIN_QUAL,
+                                      "all-to-all exchange + " if world > 1 else ""),
+                       "insertions_per_step": int(per_step), "distinct_per_gpu": int(st["distinct"]),
+                       "slots_per_gpu": int(st["slots"]), "parallelism": "hash-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_insert_items" if world > 1 else "k_build_direct",
+                         "kernel_avg_ms": kernel_avg_ms, "kernel_launches": int(klaunch),
+                         "alg_bytes_per_kmer": ALG_BYTES_PER_KMER, "kmers_per_launch": int(per_launch)},
+        }
+        if world == 1:
+            # measured random-access roofline: uniformly random 64-bit atomicCAS / load+CAS /
+            # 8-byte loads over a table of this config's size, same number of updates as one step
+            import ctypes as C
+            from quorum_amd._lib import lib, check
+            lsize = int(st["slots"]).bit_length() - 1
+            ra = {}
+            for name, mode in (("cas", 0), ("load_then_cas", 2), ("load8", 1)):
+                ms = C.c_double()
+                check(lib.qh_bench_random_access(local, lsize, int(per_launch), mode, 3, C.byref(ms)))
+                ra[name + "_per_s"] = per_launch / (ms.value * 1e-3)
+            ra["kernel_kmers_per_s"] = per_launch / (kernel_avg_ms * 1e-3) if kernel_avg_ms > 0 else 0.0
+            ra["frac_of_random_cas"] = ra["kernel_kmers_per_s"] / ra["cas_per_s"]
+            out["random_access_roofline"] = ra
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(fq, args.reads)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

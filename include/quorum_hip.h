@@ -219,6 +219,14 @@ int qh_query_dump(qh_query* q, uint64_t* mers, uint64_t* vals, uint64_t cap, uin
 
 /* -------------------------------------------------- measurement support */
 
+/* HIP-event timing of the dominant kernel of each chunk (the k-mer build / insert
+ * kernel), recorded on the stream the kernel is launched on. kernel_time returns
+ * the accumulated milliseconds and the number of timed launches since enabling.
+ * No upstream counterpart (upstream computes counted_high/low and never prints
+ * them, create_database.cc:58,88-89). */
+int qh_build_enable_timing(qh_build* h, int on);
+int qh_build_kernel_time(qh_build* h, double* total_ms, uint64_t* launches);
+
 /* Random-access roofline microbenchmark: n_updates uniformly random
  * 64-bit atomicCAS (mode 0) or 8-byte loads (mode 1) over a table of 2^lsize
  * words on `device`; returns the average kernel time of `iters` launches in

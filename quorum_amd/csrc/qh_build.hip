@@ -138,6 +138,8 @@ extern "C" void qh_build_destroy(qh_build* h) {
   void* ptrs[] = {h->table, h->d_meta, h->d_chunk, h->d_recs, h->d_tiles, h->d_ovf[0], h->d_ovf[1], h->d_items, h->d_shard_counts};
   for (void* p : ptrs) if (p) { e = hipFree(p); (void)e; }
   if (h->h_meta) { e = hipHostFree(h->h_meta); (void)e; }
+  if (h->ev0) { e = hipEventDestroy(h->ev0); (void)e; }
+  if (h->ev1) { e = hipEventDestroy(h->ev1); (void)e; }
   if (h->own_stream) { e = hipStreamDestroy(h->own_stream); (void)e; }
   delete h;
 }
@@ -222,6 +224,11 @@ extern "C" int qh_build_sync(qh_build* h) {
   QH_HIP(hipMemcpyAsync(h->h_meta, h->d_meta, sizeof(qh_meta), hipMemcpyDeviceToHost, h->stream));
   QH_HIP(hipStreamSynchronize(h->stream));
   h->pending = false;
+  if (h->timed_pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) { h->kernel_ms += ms; h->kernel_launches += 1; }
+    h->timed_pending = false;
+  }
   const qh_meta m = *h->h_meta;
   if (m.format_err) {
     const char* why = (m.format_err & QH_FMT_LINES_MOD4)     ? "line count is not a multiple of 4"
@@ -241,6 +248,32 @@ extern "C" int qh_build_sync(qh_build* h) {
   if (m.ovf_lost) rc = qh_fail(QH_EFULL, "Hash is full (overflow list exhausted)");
   else if (m.ovf_count) rc = grow_and_reinsert(h, m.ovf_count);
   if (rc) { h->failed = rc; h->failed_msg = g_last_error; }
+  return rc;
+}
+
+// HIP events around the dominant kernel of a chunk, on the stream it is launched on
+static void timing_begin(qh_build* h) {
+  if (h->timing && h->ev0) { hipError_t e = hipEventRecord(h->ev0, h->stream); (void)e; }
+}
+static void timing_end(qh_build* h) {
+  if (h->timing && h->ev1) { hipError_t e = hipEventRecord(h->ev1, h->stream); (void)e; h->timed_pending = true; }
+}
+
+extern "C" int qh_build_enable_timing(qh_build* h, int on) {
+  if (!h) return qh_fail(QH_EBADARG, "null handle");
+  int rc = qh_build_sync(h);
+  if (rc) return rc;
+  QH_HIP(hipSetDevice(h->device));
+  if (on && !h->ev0) { QH_HIP(hipEventCreate(&h->ev0)); QH_HIP(hipEventCreate(&h->ev1)); }
+  h->timing = on != 0;
+  h->kernel_ms = 0; h->kernel_launches = 0; h->timed_pending = false;
+  return QH_OK;
+}
+
+extern "C" int qh_build_kernel_time(qh_build* h, double* total_ms, uint64_t* launches) {
+  if (!h || !total_ms || !launches) return qh_fail(QH_EBADARG, "null argument");
+  int rc = qh_build_sync(h);
+  *total_ms = h->kernel_ms; *launches = h->kernel_launches;
   return rc;
 }
 
@@ -270,8 +303,10 @@ extern "C" int qh_build_add_fastq_device(qh_build* h, const void* dev_buf, size_
   if ((rc = ensure((void**)&h->d_tiles, &h->tile_cap, (ntiles + 1) * 4, "tile counts"))) return rc;
   if ((rc = ensure((void**)&h->d_recs, &h->rec_cap, rec_cap * 16, "record table"))) return rc;
   qh_launch_index_fastq((const uint8_t*)dev_buf, len, h->d_tiles, h->d_recs, (uint32_t)rec_cap, h->d_meta, h->stream);
+  timing_begin(h);
   qh_launch_build_direct((const uint8_t*)dev_buf, h->d_recs, h->d_meta, h->g, h->table, h->d_ovf[h->cur_ovf],
                          h->ovf_cap[h->cur_ovf] / 8, h->stream);
+  timing_end(h);
   QH_HIP(hipGetLastError());
   h->pending = true;
   return QH_OK;
@@ -310,8 +345,10 @@ static int submit_records(qh_build* h, const uint8_t* dev_buf, const qh_record* 
   const uint32_t n32 = (uint32_t)nrec;
   QH_HIP(hipMemcpyAsync(&h->d_meta->nrec, &n32, 4, hipMemcpyHostToDevice, h->stream));
   QH_HIP(hipStreamSynchronize(h->stream));  // recs / n32 are caller / stack memory
+  timing_begin(h);
   qh_launch_build_direct(dev_buf, h->d_recs, h->d_meta, h->g, h->table, h->d_ovf[h->cur_ovf],
                          h->ovf_cap[h->cur_ovf] / 8, h->stream);
+  timing_end(h);
   QH_HIP(hipGetLastError());
   h->pending = true;
   return QH_OK;
@@ -440,7 +477,9 @@ extern "C" int qh_build_add_mers_device(qh_build* h, const uint64_t* dev_items, 
   if (!dev_items) return qh_fail(QH_EBADARG, "null items");
   int rc = begin_chunk(h, n);
   if (rc) return rc;
+  timing_begin(h);
   qh_launch_insert_items(dev_items, n, 1, h->d_meta, h->g, h->table, h->d_ovf[h->cur_ovf], h->ovf_cap[h->cur_ovf] / 8, h->stream);
+  timing_end(h);
   QH_HIP(hipGetLastError());
   h->pending = true;
   return QH_OK;

@@ -24,6 +24,11 @@ struct qh_build {
   qh_meta* h_meta = nullptr;  // pinned mirror
   qh_build_stats st;
   bool pending = false;       // kernels of a chunk are in flight, meta not yet collected
+  // optional timing of the dominant kernel (insert/build) with HIP events on `stream`
+  bool timing = false, timed_pending = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double kernel_ms = 0;
+  uint64_t kernel_launches = 0;
   int failed = 0;             // sticky fatal status (QH_EFULL ...)
   std::string failed_msg;
 };

@@ -1,0 +1,101 @@
+"""Hash-sharded multi-GPU build: one process per GPU, k-mers
+hash-partitioned by owner shard and exchanged with ONE variable-size all-to-all
+(torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the
+CPU tests), then inserted into the local shard. The reference has no counterpart
+(single process, pthreads: src/create_database.cc:122).
+
+torch is plumbing here: device buffers, the collective and streams. Extraction,
+bucketing and insertion are the library's kernels (include/quorum_hip.h)."""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+MIX_C1 = np.uint64(0xff51afd7ed558ccd)
+MIX_C2 = np.uint64(0xc4ceb9fe1a85ec53)
+
+
+def mix_np(x, k):
+    """qh_mix (quorum_amd/csrc/qh_spec.h) on a uint64 array: the position hash whose low
+    shard_bits select the owner shard"""
+    x = np.asarray(x, dtype=np.uint64).copy()
+    n = 2 * k
+    s = np.uint64((n + 1) >> 1)
+    m = np.uint64((1 << n) - 1)
+    with np.errstate(over="ignore"):
+        x ^= x >> s
+        x = (x * MIX_C1) & m
+        x ^= x >> s
+        x = (x * MIX_C2) & m
+        x ^= x >> s
+    return x
+
+
+def owner_np(mers, k, shard_bits):
+    return (mix_np(mers, k) & np.uint64((1 << shard_bits) - 1)).astype(np.int64)
+
+
+def exchange_items(send, send_counts, group=None):
+    """One all-to-all(v) of packed items (mer<<1|hq as int64).
+
+    send: 1-D int64 tensor, the items for rank 0, then rank 1, ... back to back;
+    send_counts: python list of per-destination counts. Returns (recv, recv_counts).
+    Works on CUDA tensors (RCCL) and CPU tensors (gloo)."""
+    world = dist.get_world_size(group)
+    dev = send.device
+    sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
+    rc = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(rc, sc, group=group)
+    recv_counts = rc.tolist()
+    recv = torch.empty(int(sum(recv_counts)), dtype=torch.int64, device=dev)
+    dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=list(send_counts), group=group)
+    return recv, recv_counts
+
+
+class ShardedBuilder:
+    """Per-rank driver: extract+bucket the local chunk, exchange, insert what this shard owns."""
+
+    def __init__(self, k, bits, total_size, min_qual, rank, world, device, reprobe_limit=126, group=None):
+        from .mer_database import HashWithQuality
+        assert world & (world - 1) == 0, "number of shards must be a power of two"
+        self.k, self.rank, self.world, self.group = k, rank, world, group
+        self.shard_bits = int(math.log2(world))
+        self.device = torch.device("cuda", device)
+        self.h = HashWithQuality(total_size, 2 * k, bits, min_qual=min_qual, device=device,
+                                 reprobe_limit=reprobe_limit, shard_bits=self.shard_bits, shard_id=rank)
+        self.h.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self._buckets = None
+        self._counts = torch.zeros(world, dtype=torch.int64, device=self.device)
+
+    def _ensure(self, cap):
+        if self._buckets is None or self._buckets.shape[1] < cap:
+            self._buckets = torch.empty((self.world, cap), dtype=torch.int64, device=self.device)
+
+    def add_fastq_device(self, chunk, max_items=None):
+        """chunk: 1-D uint8 CUDA tensor holding strict 4-line FASTQ records"""
+        from ._lib import lib, check
+        nbytes = chunk.numel()
+        if max_items is None:
+            max_items = nbytes // 2
+        if self.world == 1:
+            self.h.add_fastq_device(chunk.data_ptr(), nbytes)
+            return
+        cap = int(max_items / self.world * 1.25) + 4096
+        self._ensure(cap)
+        check(lib.qh_build_extract_partitioned_device(self.h._h, C.c_void_p(chunk.data_ptr()), nbytes,
+                                                      C.c_void_p(self._buckets.data_ptr()), self._buckets.shape[1],
+                                                      C.c_void_p(self._counts.data_ptr())))
+        counts = self._counts.tolist()
+        send = torch.cat([self._buckets[s, :counts[s]] for s in range(self.world)])
+        recv, _ = exchange_items(send, counts, self.group)
+        if recv.numel():
+            self.h.add_mers_device(recv.data_ptr(), recv.numel())
+            self.h.sync()  # recv must stay alive until the insert kernel has consumed it
+
+    def reset(self):
+        self.h.reset()
+
+    def finish(self):
+        return self.h.done()

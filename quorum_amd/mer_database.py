@@ -111,6 +111,15 @@ class HashWithQuality:
     def sync(self):
         check(lib.qh_build_sync(self._h))
 
+    def enable_timing(self, on=True):
+        check(lib.qh_build_enable_timing(self._h, 1 if on else 0))
+
+    def kernel_time(self):
+        """(total ms, launches) of the dominant kernel since enable_timing()"""
+        ms, n = C.c_double(), C.c_uint64()
+        check(lib.qh_build_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def reset(self):
         check(lib.qh_build_reset(self._h))
 

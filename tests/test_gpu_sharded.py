@@ -1,0 +1,76 @@
+"""The hash-sharded build on one GPU: 2^b shard handles in one process play the b-GPU
+ranks (the RCCL collective itself is covered by tests/test_dist_cpu.py over gloo).
+Checks bucketing by owner, per-shard insertion, shard growth, and that the shards
+serialise into ONE database file that database_query reads back bit-exactly."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import pyoracle as po
+import quorum_amd as qa
+from quorum_amd import _lib, synth
+from quorum_amd.dist_build import owner_np
+from helpers import sorted_pairs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shard_bits", [1, 2, 3])
+def test_sharded_build_single_process(shard_bits, tmp_path):
+    k, bits, thresh = 24, 7, 38
+    n = 1 << shard_bits
+    g = synth.make_genome(200_000)
+    fq = synth.make_fastq(g, 40_000, 100, tails=True)
+    chunk = torch.from_numpy(fq).to("cuda:0")
+    total_size = 1 << 21
+    hs = [qa.HashWithQuality(total_size, 2 * k, bits, min_qual=thresh, shard_bits=shard_bits, shard_id=s) for s in range(n)]
+    cap = fq.size // 2
+    buckets = torch.zeros((n, cap), dtype=torch.int64, device="cuda:0")
+    counts = torch.zeros(n, dtype=torch.int64, device="cuda:0")
+    _lib.check(_lib.lib.qh_build_extract_partitioned_device(hs[0]._h, C.c_void_p(chunk.data_ptr()), chunk.numel(),
+                                                            C.c_void_p(buckets.data_ptr()), cap, C.c_void_p(counts.data_ptr())))
+    cnt = counts.tolist()
+    db = po.OracleDB(total_size, k, bits)
+    ninst = db.add_fastq(fq.tobytes(), thresh, threads=8)
+    assert sum(cnt) == ninst
+    for s in range(n):
+        items = buckets[s, :cnt[s]].cpu().numpy().view(np.uint64)
+        assert (owner_np(items >> np.uint64(1), k, shard_bits) == s).all()   # python restatement == device owner
+        hs[s].add_mers_device(buckets[s].data_ptr(), cnt[s])
+        hs[s].sync()
+    om, ov = db.sorted_dump()
+    dumps = [h.dump() for h in hs]
+    m = np.concatenate([d[0] for d in dumps])
+    v = np.concatenate([d[1] for d in dumps])
+    assert np.unique(m).size == m.size
+    sm, sv = sorted_pairs(m, v)
+    assert (sm == om).all() and (sv == ov).all()
+    # the no-exchange route: every shard scans the whole chunk and keeps what it owns
+    for s in (0, n - 1):
+        h2 = qa.HashWithQuality(total_size, 2 * k, bits, min_qual=thresh, shard_bits=shard_bits, shard_id=s)
+        h2.add_fastq_device(chunk.data_ptr(), chunk.numel())
+        st = h2.done()
+        assert st["instances"] == cnt[s] and st["instances"] + st["foreign"] == ninst
+        a, b = sorted_pairs(*h2.dump())
+        c, d = sorted_pairs(*dumps[s])
+        assert (a == c).all() and (b == d).all()
+        h2.close()
+    # one shard doubles (as after an overflow); the others are equalised before serialisation
+    lsize = int(hs[0].stats()["slots"]).bit_length() - 1
+    for h in hs:
+        _lib.check(_lib.lib.qh_build_grow_to(h._h, lsize + 1))
+        assert h.stats()["slots"] == 1 << (lsize + 1)
+    path = str(tmp_path / "sharded.db")
+    for s, h in enumerate(hs):
+        _lib.check(_lib.lib.qh_build_write_shard(h._h, path.encode(), 0, None, 1 if s == 0 else 0))
+    q = qa.DatabaseQuery(path)
+    assert q.size == n << (lsize + 1)
+    qm, qv = sorted_pairs(*q.dump())
+    assert (qm == om).all() and (qv == ov).all()
+    assert (q.lookup(om[::7]) == ov[::7]).all()
+    assert q.stats() == db.stats()
+    q.close()
+    for h in hs:
+        h.close()
