@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=READS_PER_GPU, help="reads per GPU (default: the named config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="auto", choices=["auto", "direct", "partition"], help="build strategy (A/B runs)")
+    ap.add_argument("--level1-bits", type=int, default=-1)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -83,6 +85,7 @@ def main():
     torch.cuda.synchronize()
 
     b = ShardedBuilder(K, BITS, SIZE_PER_GPU * world, MIN_QUAL, rank, world, local)
+    b.h.set_mode(args.mode, args.level1_bits)
     b.h.enable_timing(True)
 
     def step():
@@ -106,7 +109,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    kms, klaunch = b.h.kernel_time()
+    ktimes = [b.h.kernel_time(i) for i in range(4)]
     st = b.h.stats()
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -118,7 +121,11 @@ def main():
     per_step = float(inst.item())                   # insertions of ONE step over all ranks (stats are reset each step)
 
     if rank == 0:
-        kernel_avg_ms = kms / max(1, klaunch)
+        # the dominant kernel = the one with the largest average launch time (HIP events on its stream)
+        avgs = [ms / n if n else 0.0 for ms, n in ktimes]
+        dom = max(range(4), key=lambda i: avgs[i])
+        kernel_avg_ms, klaunch = avgs[dom], ktimes[dom][1]
+        knames = ("k_build_direct" if world == 1 else "k_insert_items", "k_partition<level 1>", "k_partition<level 2>", "k_window_build")
         per_launch = st["instances"]                # this rank's insertions per launch of the dominant kernel
         achieved = per_launch * ALG_BYTES_PER_KMER / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
         traffic = None
@@ -142,8 +149,9 @@ def main():
                        "slots_per_gpu": int(st["slots"]), "parallelism": "hash-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_insert_items" if world > 1 else "k_build_direct",
+                         "kernel": knames[dom],
                          "kernel_avg_ms": kernel_avg_ms, "kernel_launches": int(klaunch),
+                         "all_kernels_avg_ms": {knames[i]: avgs[i] for i in range(4) if avgs[i] > 0},
                          "alg_bytes_per_kmer": ALG_BYTES_PER_KMER, "kmers_per_launch": int(per_launch)},
         }
         if world == 1:

@@ -219,13 +219,21 @@ int qh_query_dump(qh_query* q, uint64_t* mers, uint64_t* vals, uint64_t cap, uin
 
 /* -------------------------------------------------- measurement support */
 
-/* HIP-event timing of the dominant kernel of each chunk (the k-mer build / insert
- * kernel), recorded on the stream the kernel is launched on. kernel_time returns
- * the accumulated milliseconds and the number of timed launches since enabling.
- * No upstream counterpart (upstream computes counted_high/low and never prints
- * them, create_database.cc:58,88-89). */
+/* HIP-event timing of the main kernels of each chunk, recorded on the stream the
+ * kernels are launched on. which: 0 = direct global-CAS build / item insert,
+ * 1 = partition level 1 (includes the k-mer extraction), 2 = partition level 2,
+ * 3 = LDS window build. kernel_time returns the accumulated milliseconds and the
+ * number of timed launches since enabling. No upstream counterpart (upstream
+ * computes counted_high/low and never prints them, create_database.cc:58,88-89). */
 int qh_build_enable_timing(qh_build* h, int on);
-int qh_build_kernel_time(qh_build* h, double* total_ms, uint64_t* launches);
+int qh_build_kernel_time(qh_build* h, int which, double* total_ms, uint64_t* launches);
+
+/* Build strategy: 0 = automatic, 1 = direct (every k-mer is a global 64-bit
+ * atomicCAS), 2 = radix-partitioned (k-mers are bucketed by probe window and
+ * applied in LDS). level1_bits >= 0 forces the fan-out of the first partition
+ * level (-1 = automatic). Both strategies produce the same table format and the
+ * same content. Also settable with QH_BUILD_MODE=direct|partition, QH_LEVEL1_BITS. */
+int qh_build_set_mode(qh_build* h, int mode, int level1_bits);
 
 /* Random-access roofline microbenchmark: n_updates uniformly random
  * 64-bit atomicCAS (mode 0) or 8-byte loads (mode 1) over a table of 2^lsize

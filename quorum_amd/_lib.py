@@ -76,7 +76,8 @@ SIGNATURES = [
     ("qh_query_histo", C.c_int, [_p, _u64p]),
     ("qh_query_dump", C.c_int, [_p, _u64p, _u64p, C.c_uint64, _u64p]),
     ("qh_build_enable_timing", C.c_int, [_p, C.c_int]),
-    ("qh_build_kernel_time", C.c_int, [_p, C.POINTER(C.c_double), _u64p]),
+    ("qh_build_kernel_time", C.c_int, [_p, C.c_int, C.POINTER(C.c_double), _u64p]),
+    ("qh_build_set_mode", C.c_int, [_p, C.c_int, C.c_int]),
     ("qh_bench_random_access", C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 ]
 

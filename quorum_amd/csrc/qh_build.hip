@@ -3,6 +3,7 @@
 // (src/mer_database.hpp:65-188, src/create_database.cc:44-96).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
 #include <fcntl.h>
@@ -127,6 +128,8 @@ extern "C" int qh_build_create(qh_build** out, int k, int bits, uint64_t size, i
   }
   memset(&h->st, 0, sizeof h->st);
   h->st.slots = 1ull << g.lsize;
+  if (const char* m = getenv("QH_BUILD_MODE")) h->mode = !strcmp(m, "direct") ? 1 : !strcmp(m, "partition") ? 2 : 0;
+  if (const char* b = getenv("QH_LEVEL1_BITS")) h->level1_bits = atoi(b);
   *out = h;
   return QH_OK;
 }
@@ -135,11 +138,11 @@ extern "C" void qh_build_destroy(qh_build* h) {
   if (!h) return;
   hipError_t e = hipSetDevice(h->device); (void)e;
   if (h->stream) { e = hipStreamSynchronize(h->stream); (void)e; }
-  void* ptrs[] = {h->table, h->d_meta, h->d_chunk, h->d_recs, h->d_tiles, h->d_ovf[0], h->d_ovf[1], h->d_items, h->d_shard_counts};
+  void* ptrs[] = {h->table, h->d_meta, h->d_chunk, h->d_recs, h->d_tiles, h->d_ovf[0], h->d_ovf[1], h->d_items, h->d_shard_counts, h->d_blkprefix, h->d_rbsums,
+                  h->d_bins[0], h->d_bins[1], h->d_bin_counts[0], h->d_bin_counts[1]};
   for (void* p : ptrs) if (p) { e = hipFree(p); (void)e; }
   if (h->h_meta) { e = hipHostFree(h->h_meta); (void)e; }
-  if (h->ev0) { e = hipEventDestroy(h->ev0); (void)e; }
-  if (h->ev1) { e = hipEventDestroy(h->ev1); (void)e; }
+  for (auto& pr : h->evk) for (hipEvent_t ev : pr) if (ev) { e = hipEventDestroy(ev); (void)e; }
   if (h->own_stream) { e = hipStreamDestroy(h->own_stream); (void)e; }
   delete h;
 }
@@ -195,7 +198,7 @@ static int grow_and_reinsert(qh_build* h, uint64_t n_ovf) {
     if (rc) return rc;
     if ((rc = grow_table(h, h->g.lsize + 1))) return rc;
     QH_HIP(hipMemsetAsync(h->d_meta, 0, sizeof(qh_meta), h->stream));
-    qh_launch_insert_items(h->d_ovf[src], n_ovf, 0, h->d_meta, h->g, h->table, h->d_ovf[dst], h->ovf_cap[dst] / 8, h->stream);
+    qh_launch_insert_items(h->d_ovf[src], n_ovf, nullptr, 0, 1, h->d_meta, h->g, h->table, h->d_ovf[dst], h->ovf_cap[dst] / 8, h->stream);
     QH_HIP(hipGetLastError());
     QH_HIP(hipMemcpyAsync(h->h_meta, h->d_meta, sizeof(qh_meta), hipMemcpyDeviceToHost, h->stream));
     QH_HIP(hipStreamSynchronize(h->stream));
@@ -224,10 +227,11 @@ extern "C" int qh_build_sync(qh_build* h) {
   QH_HIP(hipMemcpyAsync(h->h_meta, h->d_meta, sizeof(qh_meta), hipMemcpyDeviceToHost, h->stream));
   QH_HIP(hipStreamSynchronize(h->stream));
   h->pending = false;
-  if (h->timed_pending) {
+  for (int i = 0; i < 4; ++i) {
+    if (!h->evk_pending[i]) continue;
     float ms = 0;
-    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) { h->kernel_ms += ms; h->kernel_launches += 1; }
-    h->timed_pending = false;
+    if (hipEventElapsedTime(&ms, h->evk[i][0], h->evk[i][1]) == hipSuccess) { h->kernel_ms[i] += ms; h->kernel_launches[i] += 1; }
+    h->evk_pending[i] = false;
   }
   const qh_meta m = *h->h_meta;
   if (m.format_err) {
@@ -251,12 +255,14 @@ extern "C" int qh_build_sync(qh_build* h) {
   return rc;
 }
 
-// HIP events around the dominant kernel of a chunk, on the stream it is launched on
-static void timing_begin(qh_build* h) {
-  if (h->timing && h->ev0) { hipError_t e = hipEventRecord(h->ev0, h->stream); (void)e; }
+// HIP events around the main kernels of a chunk, on the stream they are launched on
+// (which: 0 direct build / item insert, 1 partition level 1 incl. extraction,
+//  2 partition level 2, 3 window build)
+static void timing_begin(qh_build* h, int which = 0) {
+  if (h->timing && h->evk[which][0]) { hipError_t e = hipEventRecord(h->evk[which][0], h->stream); (void)e; }
 }
-static void timing_end(qh_build* h) {
-  if (h->timing && h->ev1) { hipError_t e = hipEventRecord(h->ev1, h->stream); (void)e; h->timed_pending = true; }
+static void timing_end(qh_build* h, int which = 0) {
+  if (h->timing && h->evk[which][1]) { hipError_t e = hipEventRecord(h->evk[which][1], h->stream); (void)e; h->evk_pending[which] = true; }
 }
 
 extern "C" int qh_build_enable_timing(qh_build* h, int on) {
@@ -264,17 +270,25 @@ extern "C" int qh_build_enable_timing(qh_build* h, int on) {
   int rc = qh_build_sync(h);
   if (rc) return rc;
   QH_HIP(hipSetDevice(h->device));
-  if (on && !h->ev0) { QH_HIP(hipEventCreate(&h->ev0)); QH_HIP(hipEventCreate(&h->ev1)); }
+  if (on && !h->evk[0][0])
+    for (auto& pr : h->evk) for (hipEvent_t& ev : pr) QH_HIP(hipEventCreate(&ev));
   h->timing = on != 0;
-  h->kernel_ms = 0; h->kernel_launches = 0; h->timed_pending = false;
+  for (int i = 0; i < 4; ++i) { h->kernel_ms[i] = 0; h->kernel_launches[i] = 0; h->evk_pending[i] = false; }
   return QH_OK;
 }
 
-extern "C" int qh_build_kernel_time(qh_build* h, double* total_ms, uint64_t* launches) {
-  if (!h || !total_ms || !launches) return qh_fail(QH_EBADARG, "null argument");
+extern "C" int qh_build_kernel_time(qh_build* h, int which, double* total_ms, uint64_t* launches) {
+  if (!h || !total_ms || !launches || which < 0 || which > 3) return qh_fail(QH_EBADARG, "bad argument");
   int rc = qh_build_sync(h);
-  *total_ms = h->kernel_ms; *launches = h->kernel_launches;
+  *total_ms = h->kernel_ms[which]; *launches = h->kernel_launches[which];
   return rc;
+}
+
+extern "C" int qh_build_set_mode(qh_build* h, int mode, int level1_bits) {
+  if (!h || mode < 0 || mode > 2 || level1_bits > 12) return qh_fail(QH_EBADARG, "bad argument");
+  h->mode = mode;
+  h->level1_bits = level1_bits;
+  return QH_OK;
 }
 
 static int begin_chunk(qh_build* h, size_t max_items) {
@@ -284,6 +298,85 @@ static int begin_chunk(qh_build* h, size_t max_items) {
   rc = ensure((void**)&h->d_ovf[h->cur_ovf], &h->ovf_cap[h->cur_ovf], (max_items + 1) * 8, "overflow list");
   if (rc) return rc;
   QH_HIP(hipMemsetAsync(h->d_meta, 0, sizeof(qh_meta), h->stream));
+  return QH_OK;
+}
+
+// ------------------------------------------------- radix-partitioned chunk path
+
+// A chunk goes through the partitioned build when the table has enough 16384-slot
+// windows to fill the chip and the chunk is large enough to amortise one read+write
+// of the table (16 B/slot); small chunks into big tables stay on the direct path.
+static bool use_partition(const qh_build* h, size_t max_items) {
+  const int wid_bits = h->g.lsize - QH_WINDOW_BITS;
+  if (h->g.wbits != QH_WINDOW_BITS || wid_bits < 0 || wid_bits > 24) return false;
+  if (h->mode == 1) return false;
+  if (h->mode == 2) return true;
+  return wid_bits >= 8 && max_items >= (((size_t)1 << h->g.lsize) >> 3);
+}
+
+struct part_source {
+  const uint8_t* fastq = nullptr;    // FASTQ chunk whose record table is in h->d_recs
+  size_t rec_cap = 0;
+  const uint64_t* items = nullptr;   // or an item list
+  size_t n_items = 0;
+  int hashed = 0;
+};
+
+static int run_partitioned(qh_build* h, const part_source& src, size_t max_items) {
+  const qh_geom& g = h->g;
+  const int wid_bits = g.lsize - QH_WINDOW_BITS;
+  const uint32_t nw = 1u << wid_bits;
+  int b1 = wid_bits <= 12 ? wid_bits : (wid_bits + 1) / 2;
+  if (h->level1_bits >= 0 && h->level1_bits < wid_bits && wid_bits - h->level1_bits <= 12) b1 = h->level1_bits;
+  const int b2 = wid_bits - b1;
+  const size_t capw = max_items / nw + max_items / nw / 5 + 512;
+  const size_t cap1 = b2 ? max_items / ((size_t)1 << b1) + max_items / ((size_t)1 << b1) / 10 + 4096 : 0;
+  int rc;
+  if ((rc = ensure((void**)&h->d_bins[1], &h->bins_cap[1], (size_t)nw * capw * 8, "window buckets"))) return rc;
+  if ((rc = ensure((void**)&h->d_bin_counts[1], &h->bin_counts_cap[1], (size_t)nw * 8, "window bucket counts"))) return rc;
+  QH_HIP(hipMemsetAsync(h->d_bin_counts[1], 0, (size_t)nw * 8, h->stream));
+  if (b2) {
+    if ((rc = ensure((void**)&h->d_bins[0], &h->bins_cap[0], ((size_t)cap1 << b1) * 8, "level-1 buckets"))) return rc;
+    if ((rc = ensure((void**)&h->d_bin_counts[0], &h->bin_counts_cap[0], (size_t)8 << b1, "level-1 bucket counts"))) return rc;
+    QH_HIP(hipMemsetAsync(h->d_bin_counts[0], 0, (size_t)8 << b1, h->stream));
+  }
+  // spill list = the idle overflow buffer; failures of its direct insertion go to the active one
+  const int cur = h->cur_ovf, other = cur ^ 1;
+  if ((rc = ensure((void**)&h->d_ovf[other], &h->ovf_cap[other], (max_items + 1) * 8, "spill list"))) return rc;
+  uint64_t* spill = h->d_ovf[other];
+  const uint64_t spill_cap = h->ovf_cap[other] / 8;
+
+  qh_part_dst win_dst = {h->d_bins[1], capw, h->d_bin_counts[1], g.shard_bits + QH_WINDOW_BITS, b2 ? b2 : wid_bits,
+                         b2, spill, spill_cap};
+  qh_part_dst l1_dst = win_dst;
+  if (b2) l1_dst = {h->d_bins[0], cap1, h->d_bin_counts[0], g.shard_bits + QH_WINDOW_BITS + b2, b1, 0, spill, spill_cap};
+  else win_dst.out_bin_shift = 0;
+  const int check_owner = g.shard_bits > 0;
+
+  timing_begin(h, 1);
+  if (src.fastq) {
+    if ((rc = ensure((void**)&h->d_rbsums, &h->rbsums_cap, (src.rec_cap / 1024 + 4) * 4, "record block sums"))) return rc;
+    if ((rc = ensure((void**)&h->d_blkprefix, &h->blkprefix_cap, (src.rec_cap + 2) * 4, "record block prefix"))) return rc;
+    qh_launch_rec_blocks(h->d_recs, (uint32_t)src.rec_cap, h->d_meta, h->d_rbsums, h->d_blkprefix, h->stream);
+    qh_launch_partition_fastq(src.fastq, h->d_recs, h->d_blkprefix, h->d_meta, g, l1_dst, check_owner, h->stream);
+  } else {
+    qh_launch_partition_items(src.items, src.n_items, nullptr, 1, src.n_items, src.hashed, h->d_meta, g, l1_dst,
+                              check_owner, 1, h->stream);
+  }
+  timing_end(h, 1);
+  if (b2) {
+    timing_begin(h, 2);
+    qh_launch_partition_items(h->d_bins[0], cap1, h->d_bin_counts[0], 1u << b1, 0, 1, h->d_meta, g, win_dst, 0, 0, h->stream);
+    timing_end(h, 2);
+  }
+  timing_begin(h, 3);
+  qh_launch_window_build(h->table, g, h->d_bins[1], capw, h->d_bin_counts[1], nw, h->table_dirty ? 1 : 0, spill,
+                         spill_cap, h->d_meta, h->stream);
+  timing_end(h, 3);
+  // items that overflowed a bucket or a window's reprobe limit: plain global-CAS insertion
+  qh_launch_insert_items(spill, spill_cap, reinterpret_cast<const unsigned long long*>(&h->d_meta->spill_count), 0, 1,
+                         h->d_meta, g, h->table, h->d_ovf[cur], h->ovf_cap[cur] / 8, h->stream);
+  QH_HIP(hipGetLastError());
   return QH_OK;
 }
 
@@ -303,12 +396,20 @@ extern "C" int qh_build_add_fastq_device(qh_build* h, const void* dev_buf, size_
   if ((rc = ensure((void**)&h->d_tiles, &h->tile_cap, (ntiles + 1) * 4, "tile counts"))) return rc;
   if ((rc = ensure((void**)&h->d_recs, &h->rec_cap, rec_cap * 16, "record table"))) return rc;
   qh_launch_index_fastq((const uint8_t*)dev_buf, len, h->d_tiles, h->d_recs, (uint32_t)rec_cap, h->d_meta, h->stream);
-  timing_begin(h);
-  qh_launch_build_direct((const uint8_t*)dev_buf, h->d_recs, h->d_meta, h->g, h->table, h->d_ovf[h->cur_ovf],
-                         h->ovf_cap[h->cur_ovf] / 8, h->stream);
-  timing_end(h);
+  if (use_partition(h, len / 2)) {
+    part_source src;
+    src.fastq = (const uint8_t*)dev_buf;
+    src.rec_cap = rec_cap;
+    if ((rc = run_partitioned(h, src, len / 2))) return rc;
+  } else {
+    timing_begin(h);
+    qh_launch_build_direct((const uint8_t*)dev_buf, h->d_recs, h->d_meta, h->g, h->table, h->d_ovf[h->cur_ovf],
+                           h->ovf_cap[h->cur_ovf] / 8, h->stream);
+    timing_end(h);
+  }
   QH_HIP(hipGetLastError());
   h->pending = true;
+  h->table_dirty = true;
   return QH_OK;
 }
 
@@ -345,10 +446,18 @@ static int submit_records(qh_build* h, const uint8_t* dev_buf, const qh_record* 
   const uint32_t n32 = (uint32_t)nrec;
   QH_HIP(hipMemcpyAsync(&h->d_meta->nrec, &n32, 4, hipMemcpyHostToDevice, h->stream));
   QH_HIP(hipStreamSynchronize(h->stream));  // recs / n32 are caller / stack memory
-  timing_begin(h);
-  qh_launch_build_direct(dev_buf, h->d_recs, h->d_meta, h->g, h->table, h->d_ovf[h->cur_ovf],
-                         h->ovf_cap[h->cur_ovf] / 8, h->stream);
-  timing_end(h);
+  if (use_partition(h, max_items)) {
+    part_source src;
+    src.fastq = dev_buf;
+    src.rec_cap = nrec;
+    if ((rc = run_partitioned(h, src, max_items))) return rc;
+  } else {
+    timing_begin(h);
+    qh_launch_build_direct(dev_buf, h->d_recs, h->d_meta, h->g, h->table, h->d_ovf[h->cur_ovf],
+                           h->ovf_cap[h->cur_ovf] / 8, h->stream);
+    timing_end(h);
+  }
+  h->table_dirty = true;
   QH_HIP(hipGetLastError());
   h->pending = true;
   return QH_OK;
@@ -477,9 +586,18 @@ extern "C" int qh_build_add_mers_device(qh_build* h, const uint64_t* dev_items, 
   if (!dev_items) return qh_fail(QH_EBADARG, "null items");
   int rc = begin_chunk(h, n);
   if (rc) return rc;
-  timing_begin(h);
-  qh_launch_insert_items(dev_items, n, 1, h->d_meta, h->g, h->table, h->d_ovf[h->cur_ovf], h->ovf_cap[h->cur_ovf] / 8, h->stream);
-  timing_end(h);
+  if (use_partition(h, n)) {
+    part_source src;
+    src.items = dev_items;
+    src.n_items = n;
+    src.hashed = 0;
+    if ((rc = run_partitioned(h, src, n))) return rc;
+  } else {
+    timing_begin(h);
+    qh_launch_insert_items(dev_items, n, nullptr, 1, 0, h->d_meta, h->g, h->table, h->d_ovf[h->cur_ovf], h->ovf_cap[h->cur_ovf] / 8, h->stream);
+    timing_end(h);
+  }
+  h->table_dirty = true;
   QH_HIP(hipGetLastError());
   h->pending = true;
   return QH_OK;
@@ -557,6 +675,7 @@ extern "C" int qh_build_reset(qh_build* h) {
   memset(&h->st, 0, sizeof h->st);
   h->st.slots = slots; h->st.grows = grows;
   h->failed = 0;
+  h->table_dirty = false;
   return QH_OK;
 }
 

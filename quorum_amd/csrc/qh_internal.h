@@ -19,16 +19,25 @@ struct qh_build {
   uint64_t* d_ovf[2] = {nullptr, nullptr}; size_t ovf_cap[2] = {0, 0};  // overflow lists (bytes)
   uint64_t* d_items = nullptr; size_t items_cap = 0;  // staging of host-fed items
   uint64_t* d_shard_counts = nullptr;
+  // radix-partitioned build: block prefix of the record table, bucket levels
+  uint32_t* d_blkprefix = nullptr; size_t blkprefix_cap = 0;
+  uint32_t* d_rbsums = nullptr;    size_t rbsums_cap = 0;
+  uint64_t* d_bins[2] = {nullptr, nullptr}; size_t bins_cap[2] = {0, 0};       // level-1 / window buckets (bytes)
+  unsigned long long* d_bin_counts[2] = {nullptr, nullptr}; size_t bin_counts_cap[2] = {0, 0};
+  bool table_dirty = false;   // the table holds entries (a window must be loaded before it is updated)
+  int mode = 0;               // 0 auto, 1 direct global-CAS build, 2 radix-partitioned LDS build
+  int level1_bits = -1;       // -1 auto: buckets of the first partition level (QH_LEVEL1_BITS)
   int cur_ovf = 0;
   qh_meta* d_meta = nullptr;
   qh_meta* h_meta = nullptr;  // pinned mirror
   qh_build_stats st;
   bool pending = false;       // kernels of a chunk are in flight, meta not yet collected
   // optional timing of the dominant kernel (insert/build) with HIP events on `stream`
-  bool timing = false, timed_pending = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  double kernel_ms = 0;
-  uint64_t kernel_launches = 0;
+  bool timing = false;
+  hipEvent_t evk[4][2] = {};                 // per timed kernel: begin/end
+  bool evk_pending[4] = {false, false, false, false};
+  double kernel_ms[4] = {0, 0, 0, 0};        // 0 direct/insert, 1 partition L1 (+extraction), 2 partition L2, 3 window build
+  uint64_t kernel_launches[4] = {0, 0, 0, 0};
   int failed = 0;             // sticky fatal status (QH_EFULL ...)
   std::string failed_msg;
 };

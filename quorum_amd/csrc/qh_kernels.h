@@ -14,6 +14,7 @@ struct qh_meta {
   uint32_t ovf_lost;     // != 0: overflow list itself overflowed (fatal)
   uint32_t rehash_fail;  // != 0: a key did not fit the grown table
   uint64_t ovf_count;    // items that hit the reprobe limit (waiting for growth)
+  uint64_t spill_count;  // items that did not fit their bucket / window (inserted directly afterwards)
   uint64_t instances;    // counted_low
   uint64_t hq_instances; // counted_high
   uint64_t new_keys;     // slots claimed
@@ -36,11 +37,13 @@ void qh_launch_index_fastq(const uint8_t* buf, size_t len, uint32_t* tile_counts
 void qh_launch_build_direct(const uint8_t* buf, const uint4* recs, qh_meta* meta, const qh_geom& g,
                             uint64_t* table, uint64_t* ovf, uint64_t ovf_cap, hipStream_t s);
 
-// packed items (mer<<1|q) -> table. count_instances = 0 when re-inserting the
-// overflow list (those items were counted when first seen).
-void qh_launch_insert_items(const uint64_t* items, uint64_t n, int count_instances, qh_meta* meta,
-                            const qh_geom& g, uint64_t* table, uint64_t* ovf, uint64_t ovf_cap,
-                            hipStream_t s);
+// packed items -> table. hashed = 0: (mer<<1|q) as the C ABI passes them; 1: the
+// internal (qh_mix(mer)<<1|q) form of the overflow / spill lists. n_dev (optional) =
+// device-side count capped by n. count_instances = 0 when re-inserting items that
+// were already counted when first seen.
+void qh_launch_insert_items(const uint64_t* items, uint64_t n, const unsigned long long* n_dev,
+                            int count_instances, int hashed, qh_meta* meta, const qh_geom& g, uint64_t* table,
+                            uint64_t* ovf, uint64_t ovf_cap, hipStream_t s);
 
 // old table -> new (empty) table, carrying the value fields (mer_database.hpp:165-176)
 void qh_launch_rehash(const uint64_t* old_table, const qh_geom& og, uint64_t* new_table,
@@ -50,6 +53,30 @@ void qh_launch_rehash(const uint64_t* old_table, const qh_geom& og, uint64_t* ne
 void qh_launch_extract_partitioned(const uint8_t* buf, const uint4* recs, qh_meta* meta,
                                    const qh_geom& g, uint64_t* out, uint64_t cap_per_shard,
                                    unsigned long long* counts, hipStream_t s);
+
+// --- radix-partitioned build (qh_partition.hip) -------------------------------------
+// destination of one partition level
+struct qh_part_dst {
+  uint64_t* out;                   // buckets, out_cap items each
+  uint64_t out_cap;
+  unsigned long long* out_counts;  // fill count per bucket (zeroed by the caller)
+  int bin_shift, bin_bits;         // bucket of an item = (hash >> bin_shift) & (2^bin_bits - 1)
+  int out_bin_shift;               // output bucket = (input bucket << out_bin_shift) | bucket
+  uint64_t* spill;                 // items beyond a bucket's capacity (meta->spill_count)
+  uint64_t spill_cap;
+};
+// record table -> exclusive prefix of 64-base blocks (blk_prefix[nrec] = total);
+// tile_sums needs ceil(rec_cap/1024)+1 words
+void qh_launch_rec_blocks(const uint4* recs, uint32_t rec_cap, const qh_meta* meta, uint32_t* tile_sums,
+                          uint32_t* blk_prefix, hipStream_t s);
+void qh_launch_partition_fastq(const uint8_t* buf, const uint4* recs, const uint32_t* blk_prefix, qh_meta* meta,
+                               const qh_geom& g, const qh_part_dst& d, int check_owner, hipStream_t s);
+void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsigned long long* in_counts,
+                               uint32_t n_in_buckets, uint64_t in_n, int in_hashed, qh_meta* meta, const qh_geom& g,
+                               const qh_part_dst& d, int check_owner, int count_instances, hipStream_t s);
+void qh_launch_window_build(uint64_t* table, const qh_geom& g, const uint64_t* items, uint64_t cap,
+                            const unsigned long long* counts, uint32_t n_windows, int table_dirty, uint64_t* spill,
+                            uint64_t spill_cap, qh_meta* meta, hipStream_t s);
 
 // --- read side ------------------------------------------------------------------------
 void qh_launch_lookup(const uint64_t* table, const qh_geom& g, const uint64_t* mers, uint64_t n,

@@ -11,44 +11,9 @@
 // Everything here is integer/byte work bound by HBM (random 8-byte slot updates
 // plus a streaming pass over the chunk); there is no MFMA-shaped work.
 #include "qh_kernels.h"
+#include "qh_device.h"
 
 #define QH_BLOCK 256
-
-// ------------------------------------------------------------------ small helpers
-
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
-__device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
-  // number of set bits of `mask` in lanes below the calling lane
-  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-}
-
-// 16-bit mask of the bytes of v that equal '\n'
-__device__ __forceinline__ uint32_t nl_mask16(uint4 v) {
-  uint32_t w[4] = {v.x, v.y, v.z, v.w};
-  uint32_t m = 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const uint32_t x = w[i] ^ 0x0A0A0A0Au;
-    const uint32_t t = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);  // 0x80 at zero bytes
-    const uint32_t c = ((t >> 7) & 1u) | ((t >> 14) & 2u) | ((t >> 21) & 4u) | ((t >> 28) & 8u);
-    m |= c << (4 * i);
-  }
-  return m;
-}
-
-// 16 bytes at off (off is a multiple of 16; buf is 16-byte aligned); bytes past len read as 0
-__device__ __forceinline__ uint4 load16_guarded(const uint8_t* __restrict__ buf, size_t off, size_t len) {
-  if (off + 16 <= len) return *reinterpret_cast<const uint4*>(buf + off);
-  uint32_t w[4] = {0, 0, 0, 0};
-  for (int i = 0; i < 16; ++i)
-    if (off + i < len) w[i >> 2] |= (uint32_t)buf[off + i] << (8 * (i & 3));
-  return make_uint4(w[0], w[1], w[2], w[3]);
-}
 
 // ------------------------------------------------------- FASTQ chunk -> record table
 
@@ -194,103 +159,6 @@ void qh_launch_index_fastq(const uint8_t* buf, size_t len, uint32_t* tile_counts
   hipLaunchKernelGGL(k_validate_records, dim3(1024), dim3(QH_BLOCK), 0, s, recs, meta);
 }
 
-// ---------------------------------------------------------------- slot insertion
-
-// hash_with_quality::add on the single-word slot table. Returns false when the
-// reprobe limit is exhausted (caller queues the item for after the doubling).
-__device__ __forceinline__ bool qh_insert(const qh_geom& g, uint64_t* __restrict__ table, uint64_t home,
-                                          uint64_t tag0, uint32_t q, uint32_t* is_new) {
-  const uint64_t wmask = qh_low_mask(g.wbits);
-  const uint64_t base = home & ~wmask;
-  const uint64_t fresh = q ? 3u : 2u;  // nval of a new entry (mer_database.hpp:105-110 from 0)
-  for (uint32_t i = 0; i <= (uint32_t)g.max_reprobe; ++i) {
-    unsigned long long* slot = reinterpret_cast<unsigned long long*>(table + (base | ((home + i) & wmask)));
-    const uint64_t want = tag0 | (i + 1);
-    uint64_t old = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (;;) {
-      if (old == 0) {
-        const uint64_t prev = atomicCAS(slot, 0ull, (unsigned long long)((want << g.vbits) | fresh));
-        if (prev == 0) { *is_new = 1; return true; }
-        old = prev;
-      }
-      if ((old >> g.vbits) != want) break;  // another key lives here: next probe
-      uint64_t nv;
-      if (!qh_update_val(old & g.vmask, q, g.max_val, &nv)) return true;
-      const uint64_t nw = (old & ~g.vmask) | nv;
-      const uint64_t prev = atomicCAS(slot, (unsigned long long)old, (unsigned long long)nw);
-      if (prev == old) return true;
-      old = prev;
-    }
-  }
-  return false;
-}
-
-__device__ __forceinline__ void qh_overflow(qh_meta* __restrict__ meta, uint64_t* __restrict__ ovf,
-                                            uint64_t ovf_cap, uint64_t item) {
-  const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(&meta->ovf_count), 1ull);
-  if (at < ovf_cap) ovf[at] = item;
-  else meta->ovf_lost = 1;
-}
-
-// 32 plane bits -> even bit positions of a 64-bit word
-__device__ __forceinline__ uint64_t spread32(uint32_t v) {
-  uint64_t x = v;
-  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
-  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
-  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
-  x = (x | (x << 2)) & 0x3333333333333333ull;
-  x = (x | (x << 1)) & 0x5555555555555555ull;
-  return x;
-}
-
-// Wave-parallel form of create_database.cc:64-92 for one 64-base column block of
-// one read. Each lane owns one base; the wave's four ballots are the bit planes
-// (valid, high-quality, code bit 0, code bit 1) of 64 consecutive positions, and
-// the k-mer ending at a lane's base is the k-bit window ending at its bit of the
-// (previous block : this block) plane pair. "low_len >= k" is "valid window all
-// ones", "high_len >= k" is "hq window all ones": the registers m/rm of the
-// scalar loop never need clearing because only complete windows are emitted.
-struct qh_planes { uint64_t v, h, l0, l1; };
-
-__device__ __forceinline__ uint64_t window_top(uint64_t cur, uint64_t prev, int lane) {
-  // bit 63 = this lane's position, bit 63-i = i positions earlier
-  return (cur << (63 - lane)) | ((prev >> lane) >> 1);
-}
-
-__device__ __forceinline__ bool qh_lane_kmer(const qh_planes& cur, const qh_planes& prev, int lane, int k,
-                                             uint64_t* key, uint32_t* hq) {
-  const uint64_t kones = (1ull << k) - 1;
-  const int drop = 64 - k;
-  if ((window_top(cur.v, prev.v, lane) >> drop) != kones) return false;
-  *hq = (window_top(cur.h, prev.h, lane) >> drop) == kones;
-  const uint64_t x0 = window_top(cur.l0, prev.l0, lane), x1 = window_top(cur.l1, prev.l1, lane);
-  // forward mer: base i (i = 0 newest) is window bit 63-i -> bit-reverse
-  const uint32_t m0 = (uint32_t)(__builtin_bitreverse64(x0) & kones);
-  const uint32_t m1 = (uint32_t)(__builtin_bitreverse64(x1) & kones);
-  // reverse complement: base i = 3 - (forward base k-1-i) -> complemented window, oldest base lowest
-  const uint32_t r0 = (uint32_t)((~x0) >> drop), r1 = (uint32_t)((~x1) >> drop);
-  const uint64_t m = spread32(m0) | (spread32(m1) << 1);
-  const uint64_t rm = spread32(r0) | (spread32(r1) << 1);
-  *key = m < rm ? m : rm;  // create_database.cc:86
-  return true;
-}
-
-__device__ __forceinline__ qh_planes qh_load_planes(const uint8_t* __restrict__ buf, uint32_t s0, uint32_t q0,
-                                                    uint32_t len, uint32_t c0, int lane, int min_qual) {
-  const uint32_t j = c0 + lane;
-  const bool inb = j < len;
-  const unsigned b = inb ? buf[(size_t)s0 + j] : 0u;
-  const int ql = inb ? (int)(int8_t)buf[(size_t)q0 + j] : -128;
-  const int code = qh_code(b);
-  const bool valid = code >= 0;
-  qh_planes p;
-  p.v = __ballot(valid);
-  p.h = __ballot(valid && ql >= (int)(int8_t)min_qual);  // signed char compare, create_database.cc:81
-  p.l0 = __ballot(valid && (code & 1));
-  p.l1 = __ballot(valid && (code & 2));
-  return p;
-}
-
 // One wave per read (grid-stride). Direct build: every emitted k-mer is inserted
 // with global 64-bit CAS.
 __global__ __launch_bounds__(QH_BLOCK) void k_build_direct(const uint8_t* __restrict__ buf,
@@ -313,14 +181,15 @@ __global__ __launch_bounds__(QH_BLOCK) void k_build_direct(const uint8_t* __rest
       uint64_t key;
       uint32_t q;
       if (qh_lane_kmer(cur, prev, lane, g.k, &key, &q)) {
-        const qh_pos p = qh_locate(g, key);
+        const uint64_t h = qh_mix(key, g.k);
+        const qh_pos p = qh_locate_hash(g, h);
         if (p.shard != (uint32_t)g.shard_id) {
           ++n_foreign;
         } else {
           ++n_inst;
           n_hq += q;
           uint32_t is_new = 0;
-          if (!qh_insert(g, table, p.home, p.tag0, q, &is_new)) qh_overflow(meta, ovf, ovf_cap, (key << 1) | q);
+          if (!qh_insert(g, table, p.home, p.tag0, q, &is_new)) qh_overflow(meta, ovf, ovf_cap, (h << 1) | q);
           n_new += is_new;
         }
       }
@@ -342,23 +211,27 @@ void qh_launch_build_direct(const uint8_t* buf, const uint4* recs, qh_meta* meta
   hipLaunchKernelGGL(k_build_direct, dim3(2048), dim3(QH_BLOCK), 0, s, buf, recs, meta, g, table, ovf, ovf_cap);
 }
 
-// packed items (mer << 1 | q): one lane per item
+// packed items, one lane per item: (mer << 1 | q) as the C ABI passes them, or the
+// internal hashed form (qh_mix(mer) << 1 | q) of the overflow / spill lists.
+// n_dev (optional): device-side item count (the spill list's), capped by n.
 __global__ __launch_bounds__(QH_BLOCK) void k_insert_items(const uint64_t* __restrict__ items, uint64_t n,
+                                                           const unsigned long long* __restrict__ n_dev,
                                                            qh_meta* __restrict__ meta, const qh_geom g,
                                                            uint64_t* __restrict__ table,
                                                            uint64_t* __restrict__ ovf, uint64_t ovf_cap,
-                                                           int count_instances) {
+                                                           int count_instances, int hashed) {
+  if (n_dev) { const unsigned long long nd = *n_dev; n = nd < n ? nd : n; }
   const int lane = threadIdx.x & 63;
   uint32_t n_inst = 0, n_hq = 0, n_new = 0, n_foreign = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t it = items[i];
-    const uint64_t key = (it >> 1) & g.kmask;
     const uint32_t q = (uint32_t)(it & 1);
-    const qh_pos p = qh_locate(g, key);
+    const uint64_t h = hashed ? ((it >> 1) & g.kmask) : qh_mix((it >> 1) & g.kmask, g.k);
+    const qh_pos p = qh_locate_hash(g, h);
     if (p.shard != (uint32_t)g.shard_id) { ++n_foreign; continue; }
     ++n_inst; n_hq += q;
     uint32_t is_new = 0;
-    if (!qh_insert(g, table, p.home, p.tag0, q, &is_new)) qh_overflow(meta, ovf, ovf_cap, it);
+    if (!qh_insert(g, table, p.home, p.tag0, q, &is_new)) qh_overflow(meta, ovf, ovf_cap, (h << 1) | q);
     n_new += is_new;
   }
   n_inst = wave_sum_u32(n_inst); n_hq = wave_sum_u32(n_hq);
@@ -379,11 +252,11 @@ static inline unsigned grid_for(uint64_t n, unsigned block, unsigned max_blocks)
   return (unsigned)(b > max_blocks ? max_blocks : b);
 }
 
-void qh_launch_insert_items(const uint64_t* items, uint64_t n, int count_instances, qh_meta* meta,
-                            const qh_geom& g, uint64_t* table, uint64_t* ovf, uint64_t ovf_cap,
-                            hipStream_t s) {
-  hipLaunchKernelGGL(k_insert_items, dim3(grid_for(n, QH_BLOCK, 4096)), dim3(QH_BLOCK), 0, s, items, n, meta, g,
-                     table, ovf, ovf_cap, count_instances);
+void qh_launch_insert_items(const uint64_t* items, uint64_t n, const unsigned long long* n_dev,
+                            int count_instances, int hashed, qh_meta* meta, const qh_geom& g, uint64_t* table,
+                            uint64_t* ovf, uint64_t ovf_cap, hipStream_t s) {
+  hipLaunchKernelGGL(k_insert_items, dim3(grid_for(n, QH_BLOCK, 4096)), dim3(QH_BLOCK), 0, s, items, n, n_dev, meta,
+                     g, table, ovf, ovf_cap, count_instances, hashed);
 }
 
 // old slot -> new table; the value field is carried over (mer_database.hpp:170-176)
@@ -395,9 +268,8 @@ __global__ __launch_bounds__(QH_BLOCK) void k_rehash(const uint64_t* __restrict_
   for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t s = old_table[idx];
     if (!s) continue;
-    const uint64_t key = qh_slot_key(og, s, idx);
     const uint64_t val = s & og.vmask;
-    const qh_pos p = qh_locate(ng, key);
+    const qh_pos p = qh_locate_hash(ng, qh_slot_hash(og, s, idx));
     const uint64_t base = p.home & ~wmask;
     bool done = false;
     for (uint32_t i = 0; i <= (uint32_t)ng.max_reprobe && !done; ++i) {

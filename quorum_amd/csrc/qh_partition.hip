@@ -1,0 +1,446 @@
+// qh_partition.hip -- the radix-partitioned build: the same hash_with_quality::add
+// (src/mer_database.hpp:94-113) over the same table as qh_kernels.hip's direct path,
+// restructured so that no k-mer update is a global atomic.
+//
+// Why: a device-scope 64-bit atomicCAS on MI355X executes at the memory side at
+// ~22 G/s chip-wide whatever the footprint (measured, profiles/r01_v1_direct), and
+// each one moves a 64-B line in and out of HBM for 8 useful bytes. Here the items
+// of a chunk are first bucketed by the 16384-slot probe WINDOW their key hashes to
+// (coalesced streaming writes staged through LDS, one global atomic per
+// (tile, bucket)), then one workgroup per window pulls the window's 128 KiB into
+// LDS, applies its bucket with LDS compare-and-swap, and streams the window back.
+// HBM sees only streaming traffic: 8 B/item written + 8 B/item read per level plus
+// one read+write of the table.
+//
+//   k_rec_blocks_*     record table -> exclusive prefix of 64-base blocks per record
+//   k_partition<SRC>   FASTQ records (fused k-mer extraction, create_database.cc:64-92)
+//                      or an item list -> buckets by a bit field of the hash
+//   k_window_build     bucket -> LDS window -> table
+#include "qh_kernels.h"
+#include "qh_device.h"
+
+#define QP_THREADS 1024
+#define QP_WAVES (QP_THREADS / 64)
+#define QP_BLOCKS_PER_WAVE 12
+#define QP_TILE_BLOCKS (QP_WAVES * QP_BLOCKS_PER_WAVE)  // 192 blocks of 64 positions
+#define QP_TILE_ITEMS (QP_TILE_BLOCKS * 64)             // 12288 items = 96 KiB of LDS
+#define QP_MAX_BINS 4096
+#define QP_NONE (~0ull)
+
+// ------------------------------------------- blocks-per-record prefix (3 small kernels)
+
+#define RB_TILE 1024  // records per scan tile
+
+__global__ __launch_bounds__(256) void k_rec_blocks_sum(const uint4* __restrict__ recs, const qh_meta* __restrict__ meta,
+                                                        uint32_t* __restrict__ tile_sums) {
+  __shared__ uint32_t ws[4];
+  const uint32_t nrec = meta->format_err ? 0 : meta->nrec;
+  const uint32_t base = blockIdx.x * RB_TILE;
+  uint32_t s = 0;
+  for (uint32_t r = base + threadIdx.x; r < base + RB_TILE && r < nrec; r += 256) s += (recs[r].y + 63) >> 6;
+  s = wave_sum_u32(s);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// exclusive scan of n u32 values in place by one workgroup; the total goes to *total
+__global__ __launch_bounds__(1024) void k_scan_u32(uint32_t* __restrict__ v, uint32_t n, uint32_t* __restrict__ total) {
+  __shared__ uint32_t part[1024];
+  const uint32_t per = (n + 1023) / 1024;
+  const uint32_t b = threadIdx.x * per;
+  uint32_t s = 0;
+  for (uint32_t i = b; i < b + per && i < n; ++i) s += v[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (uint32_t o = 1; o < 1024; o <<= 1) {
+    const uint32_t x = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+    __syncthreads();
+    part[threadIdx.x] += x;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - s;
+  for (uint32_t i = b; i < b + per && i < n; ++i) {
+    const uint32_t c = v[i];
+    v[i] = run;
+    run += c;
+  }
+  if (threadIdx.x == 1023) *total = part[1023];
+}
+
+__global__ __launch_bounds__(256) void k_rec_blocks_apply(const uint4* __restrict__ recs, const qh_meta* __restrict__ meta,
+                                                          const uint32_t* __restrict__ tile_prefix,
+                                                          const uint32_t* __restrict__ total,
+                                                          uint32_t* __restrict__ blk_prefix) {
+  __shared__ uint32_t wtot[4];
+  const uint32_t nrec = meta->format_err ? 0 : meta->nrec;
+  const uint32_t base = blockIdx.x * RB_TILE;
+  if (base >= nrec) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) blk_prefix[0] = 0;  // nrec == 0
+    return;
+  }
+  uint32_t run = tile_prefix[blockIdx.x];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (uint32_t j = 0; j < RB_TILE; j += 256) {
+    const uint32_t r = base + j + threadIdx.x;
+    const uint32_t c = r < nrec ? (recs[r].y + 63) >> 6 : 0;
+    uint32_t inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t x = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += x;
+    }
+    if (lane == 63) wtot[wv] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t x = wtot[w];
+      if (w < wv) wbase += x;
+      tot += x;
+    }
+    if (r < nrec) blk_prefix[r] = run + wbase + inc - c;
+    run += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && base + RB_TILE >= nrec) blk_prefix[nrec] = *total;
+}
+
+void qh_launch_rec_blocks(const uint4* recs, uint32_t rec_cap, const qh_meta* meta, uint32_t* tile_sums,
+                          uint32_t* blk_prefix, hipStream_t s) {
+  const uint32_t ntiles = (rec_cap + RB_TILE - 1) / RB_TILE;
+  // tile_sums[ntiles] receives the total
+  hipLaunchKernelGGL(k_rec_blocks_sum, dim3(ntiles), dim3(256), 0, s, recs, meta, tile_sums);
+  hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, tile_sums, ntiles, tile_sums + ntiles);
+  hipLaunchKernelGGL(k_rec_blocks_apply, dim3(ntiles), dim3(256), 0, s, recs, meta, tile_sums, tile_sums + ntiles, blk_prefix);
+}
+
+// ------------------------------------------------------------- LDS-staged multi-split
+
+struct qp_params {
+  // destination buckets: bucket ob holds out[ob * out_cap ...], its fill count in out_counts[ob]
+  uint64_t* out;
+  uint64_t out_cap;
+  unsigned long long* out_counts;
+  int bin_shift;       // bin = (h >> bin_shift) & bin_mask
+  uint32_t bin_mask;
+  int out_bin_shift;   // ob = (input bucket << out_bin_shift) | bin
+  uint64_t* spill;     // items that do not fit their bucket (meta->spill_count), inserted directly later
+  uint64_t spill_cap;
+  qh_meta* meta;
+  int check_owner;     // drop (and count) items whose owner shard is not g.shard_id
+  int count_instances; // add emitted items to meta->instances / hq_instances
+  // SRC_FASTQ
+  const uint8_t* buf;
+  const uint4* recs;
+  const uint32_t* blk_prefix;
+  // SRC_ITEMS: input bucket b = blockIdx.y holds in[b * in_cap ...], in_counts[b] items (or in_n when in_counts == 0)
+  const uint64_t* in;
+  uint64_t in_cap;
+  const unsigned long long* in_counts;
+  uint64_t in_n;
+  int in_hashed;       // 0: (mer<<1|q) as the C ABI passes them, 1: (hash<<1|q)
+};
+
+enum { QP_SRC_FASTQ = 0, QP_SRC_ITEMS = 1 };
+
+__device__ __forceinline__ void qp_spill(const qp_params& p, uint64_t item) {
+  const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(&p.meta->spill_count), 1ull);
+  if (at < p.spill_cap) p.spill[at] = item;
+  else p.meta->ovf_lost = 1;
+}
+
+template <int SRC>
+__global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, const qh_geom g) {
+  __shared__ uint64_t sorted[QP_TILE_ITEMS];
+  __shared__ uint32_t cursor[QP_MAX_BINS];  // histogram, then running placement cursor
+  __shared__ uint32_t offs[QP_MAX_BINS];    // exclusive prefix of the histogram
+  __shared__ uint32_t gbase[QP_MAX_BINS];   // reserved start inside the global bucket
+  __shared__ uint32_t wsum[QP_WAVES];
+  __shared__ uint32_t s_total;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t nbins = p.bin_mask + 1;
+  const uint32_t smask = (uint32_t)qh_low_mask(g.shard_bits);
+  uint32_t n_inst = 0, n_hq = 0, n_foreign = 0;
+
+  uint64_t ntiles;
+  uint32_t nrec = 0, nblk = 0;
+  const uint64_t* src = nullptr;
+  uint64_t src_n = 0;
+  if (SRC == QP_SRC_FASTQ) {
+    if (p.meta->format_err) return;
+    nrec = p.meta->nrec;
+    nblk = p.blk_prefix[nrec];
+    ntiles = (nblk + QP_TILE_BLOCKS - 1) / QP_TILE_BLOCKS;
+  } else {
+    src = p.in + (uint64_t)blockIdx.y * p.in_cap;
+    src_n = p.in_counts ? (uint64_t)p.in_counts[blockIdx.y] : p.in_n;
+    if (src_n > p.in_cap) src_n = p.in_cap;
+    ntiles = (src_n + QP_TILE_ITEMS - 1) / QP_TILE_ITEMS;
+  }
+  const uint32_t in_bucket = SRC == QP_SRC_ITEMS ? blockIdx.y : 0;
+
+  for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (uint32_t b = tid; b < nbins; b += QP_THREADS) cursor[b] = 0;
+    __syncthreads();
+
+    // ---- pass 1: produce this wave's items (kept in registers) and the tile histogram
+    uint64_t it[QP_BLOCKS_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < QP_BLOCKS_PER_WAVE; ++i) it[i] = QP_NONE;
+
+    if (SRC == QP_SRC_FASTQ) {
+      const uint32_t g0 = (uint32_t)tile * QP_TILE_BLOCKS + wave * QP_BLOCKS_PER_WAVE;
+      if (g0 < nblk) {
+        // record of block g0: the largest r with blk_prefix[r] <= g0
+        uint32_t lo = 0, hi = nrec;  // invariant: blk_prefix[lo] <= g0 < blk_prefix[hi]
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (p.blk_prefix[mid] <= g0) lo = mid; else hi = mid;
+        }
+        uint32_t r = __builtin_amdgcn_readfirstlane(lo);
+        uint4 rc = p.recs[r];
+        uint32_t rbeg = p.blk_prefix[r], rend = p.blk_prefix[r + 1];
+        qh_planes prev = {0, 0, 0, 0};
+        bool have_prev = false;
+#pragma unroll
+        for (int i = 0; i < QP_BLOCKS_PER_WAVE; ++i) {
+          const uint32_t gb = g0 + i;
+          if (gb < nblk) {
+            while (gb >= rend) {  // next record (records without blocks are skipped)
+              ++r;
+              rc = p.recs[r];
+              rbeg = rend;
+              rend = p.blk_prefix[r + 1];
+              have_prev = false;
+            }
+            const uint32_t j = gb - rbeg;
+            if (j == 0) prev = qh_planes{0, 0, 0, 0};
+            else if (!have_prev) prev = qh_load_planes(p.buf, rc.x, rc.z, rc.y, (j - 1) * 64, lane, g.min_qual);
+            const qh_planes cur = qh_load_planes(p.buf, rc.x, rc.z, rc.y, j * 64, lane, g.min_qual);
+            uint64_t key;
+            uint32_t q;
+            if (qh_lane_kmer(cur, prev, lane, g.k, &key, &q)) {
+              const uint64_t h = qh_mix(key, g.k);
+              if (p.check_owner && ((uint32_t)h & smask) != (uint32_t)g.shard_id) {
+                ++n_foreign;
+              } else {
+                ++n_inst; n_hq += q;
+                it[i] = (h << 1) | q;
+                atomicAdd(&cursor[(uint32_t)(h >> p.bin_shift) & p.bin_mask], 1u);
+              }
+            }
+            prev = cur;
+            have_prev = true;
+          }
+        }
+      }
+    } else {
+      const uint64_t j0 = tile * QP_TILE_ITEMS + (uint64_t)wave * (QP_BLOCKS_PER_WAVE * 64) + lane;
+#pragma unroll
+      for (int i = 0; i < QP_BLOCKS_PER_WAVE; ++i) {
+        const uint64_t j = j0 + (uint64_t)i * 64;
+        if (j < src_n) {
+          const uint64_t raw = src[j];
+          const uint32_t q = (uint32_t)(raw & 1);
+          const uint64_t h = p.in_hashed ? ((raw >> 1) & g.kmask) : qh_mix((raw >> 1) & g.kmask, g.k);
+          if (p.check_owner && ((uint32_t)h & smask) != (uint32_t)g.shard_id) {
+            ++n_foreign;
+          } else {
+            ++n_inst; n_hq += q;
+            it[i] = (h << 1) | q;
+            atomicAdd(&cursor[(uint32_t)(h >> p.bin_shift) & p.bin_mask], 1u);
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- exclusive scan of the histogram (4 bins per thread), bucket space reservation
+    {
+      uint32_t c[4], s = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t b = tid * 4 + e;
+        c[e] = b < nbins ? cursor[b] : 0;
+        s += c[e];
+      }
+      uint32_t inc = s;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t x = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += x;
+      }
+      if (lane == 63) wsum[wave] = inc;
+      __syncthreads();
+      uint32_t wbase = 0, tot = 0;
+#pragma unroll
+      for (int w = 0; w < QP_WAVES; ++w) {
+        const uint32_t x = wsum[w];
+        if (w < wave) wbase += x;
+        tot += x;
+      }
+      if (tid == 0) s_total = tot;
+      uint32_t run = wbase + inc - s;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t b = tid * 4 + e;
+        if (b < nbins) {
+          offs[b] = run;
+          cursor[b] = run;
+          gbase[b] = c[e] ? (uint32_t)atomicAdd(&p.out_counts[((uint64_t)in_bucket << p.out_bin_shift) | b],
+                                                (unsigned long long)c[e])
+                          : 0u;
+          run += c[e];
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- pass 2: place the items bucket-sorted into LDS
+#pragma unroll
+    for (int i = 0; i < QP_BLOCKS_PER_WAVE; ++i) {
+      if (it[i] != QP_NONE) {
+        const uint32_t b = (uint32_t)((it[i] >> 1) >> p.bin_shift) & p.bin_mask;
+        sorted[atomicAdd(&cursor[b], 1u)] = it[i];
+      }
+    }
+    __syncthreads();
+
+    // ---- stream the tile out: consecutive lanes of one bucket write consecutive words
+    const uint32_t total = s_total;
+    for (uint32_t j = tid; j < total; j += QP_THREADS) {
+      const uint64_t v = sorted[j];
+      const uint32_t b = (uint32_t)((v >> 1) >> p.bin_shift) & p.bin_mask;
+      const uint64_t dst = (uint64_t)gbase[b] + (j - offs[b]);
+      if (dst < p.out_cap) p.out[(((uint64_t)in_bucket << p.out_bin_shift) | b) * p.out_cap + dst] = v;
+      else qp_spill(p, v);
+    }
+    __syncthreads();
+  }
+
+  if (p.count_instances) {
+    n_inst = wave_sum_u32(n_inst); n_hq = wave_sum_u32(n_hq); n_foreign = wave_sum_u32(n_foreign);
+    if (lane == 0) {
+      if (n_inst) atomicAdd(reinterpret_cast<unsigned long long*>(&p.meta->instances), (unsigned long long)n_inst);
+      if (n_hq) atomicAdd(reinterpret_cast<unsigned long long*>(&p.meta->hq_instances), (unsigned long long)n_hq);
+      if (n_foreign) atomicAdd(reinterpret_cast<unsigned long long*>(&p.meta->foreign), (unsigned long long)n_foreign);
+    }
+  }
+}
+
+static void fill_common(qp_params& p, const qh_part_dst& d, qh_meta* meta, int check_owner, int count_instances) {
+  p.out = d.out; p.out_cap = d.out_cap; p.out_counts = d.out_counts;
+  p.bin_shift = d.bin_shift; p.bin_mask = (1u << d.bin_bits) - 1; p.out_bin_shift = d.out_bin_shift;
+  p.spill = d.spill; p.spill_cap = d.spill_cap; p.meta = meta;
+  p.check_owner = check_owner; p.count_instances = count_instances;
+}
+
+void qh_launch_partition_fastq(const uint8_t* buf, const uint4* recs, const uint32_t* blk_prefix, qh_meta* meta,
+                               const qh_geom& g, const qh_part_dst& d, int check_owner, hipStream_t s) {
+  qp_params p = {};
+  fill_common(p, d, meta, check_owner, 1);
+  p.buf = buf; p.recs = recs; p.blk_prefix = blk_prefix;
+  hipLaunchKernelGGL(k_partition<QP_SRC_FASTQ>, dim3(256), dim3(QP_THREADS), 0, s, p, g);
+}
+
+void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsigned long long* in_counts,
+                               uint32_t n_in_buckets, uint64_t in_n, int in_hashed, qh_meta* meta, const qh_geom& g,
+                               const qh_part_dst& d, int check_owner, int count_instances, hipStream_t s) {
+  qp_params p = {};
+  fill_common(p, d, meta, check_owner, count_instances);
+  p.in = in; p.in_cap = in_cap; p.in_counts = in_counts; p.in_n = in_n; p.in_hashed = in_hashed;
+  const uint64_t most = in_counts ? in_cap : in_n;
+  uint64_t tiles = (most + QP_TILE_ITEMS - 1) / QP_TILE_ITEMS;
+  if (tiles < 1) tiles = 1;
+  // one workgroup per CU is resident (144 KiB of LDS): grid-stride the tiles of a bucket
+  uint64_t gx = n_in_buckets >= 256 ? 1 : (256 + n_in_buckets - 1) / n_in_buckets * 2;
+  if (gx > tiles) gx = tiles;
+  hipLaunchKernelGGL(k_partition<QP_SRC_ITEMS>, dim3((unsigned)gx, n_in_buckets), dim3(QP_THREADS), 0, s, p, g);
+}
+
+// ----------------------------------------------------------------- window build
+
+// hash_with_quality::add on a window held in LDS (same slot format and probe rule as
+// qh_insert, local index instead of a global one)
+__device__ __forceinline__ bool qh_insert_lds(const qh_geom& g, uint64_t* win, uint32_t loc, uint64_t tag0,
+                                              uint32_t q, uint32_t* is_new) {
+  const uint32_t wmask = (1u << QH_WINDOW_BITS) - 1;
+  const uint64_t fresh = q ? 3u : 2u;
+  for (uint32_t i = 0; i <= (uint32_t)g.max_reprobe; ++i) {
+    unsigned long long* slot = reinterpret_cast<unsigned long long*>(win + ((loc + i) & wmask));
+    const uint64_t want = tag0 | (i + 1);
+    uint64_t old = *reinterpret_cast<volatile unsigned long long*>(slot);
+    for (;;) {
+      if (old == 0) {
+        const uint64_t prev = atomicCAS(slot, 0ull, (unsigned long long)((want << g.vbits) | fresh));
+        if (prev == 0) { *is_new = 1; return true; }
+        old = prev;
+      }
+      if ((old >> g.vbits) != want) break;
+      uint64_t nv;
+      if (!qh_update_val(old & g.vmask, q, g.max_val, &nv)) return true;
+      const uint64_t prev = atomicCAS(slot, (unsigned long long)old, (unsigned long long)((old & ~g.vmask) | nv));
+      if (prev == old) return true;
+      old = prev;
+    }
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restrict__ table, const qh_geom g,
+                                                             const uint64_t* __restrict__ items, uint64_t cap,
+                                                             const unsigned long long* __restrict__ counts,
+                                                             int table_dirty, uint64_t* __restrict__ spill,
+                                                             uint64_t spill_cap, qh_meta* __restrict__ meta) {
+  __shared__ uint64_t win[1u << QH_WINDOW_BITS];
+  __shared__ uint32_t wnew[QP_WAVES];
+  const uint32_t w = blockIdx.x;
+  uint64_t n = counts[w];
+  if (n > cap) n = cap;
+  if (n == 0) return;  // nothing to add: the window stays as it is
+  const int tid = threadIdx.x;
+  uint4* tw = reinterpret_cast<uint4*>(table + ((uint64_t)w << QH_WINDOW_BITS));
+  uint4* lw = reinterpret_cast<uint4*>(win);
+  const uint32_t nvec = (1u << QH_WINDOW_BITS) / 2;  // 16-byte pieces
+  if (table_dirty) {
+    for (uint32_t i = tid; i < nvec; i += QP_THREADS) lw[i] = tw[i];
+  } else {
+    for (uint32_t i = tid; i < nvec; i += QP_THREADS) lw[i] = make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();
+  const uint64_t* src = items + (uint64_t)w * cap;
+  const int gsize = g.lsize + g.shard_bits;
+  uint32_t n_new = 0;
+  for (uint64_t j = tid; j < n; j += QP_THREADS) {
+    const uint64_t v = src[j];
+    const uint64_t h = v >> 1;
+    const uint32_t q = (uint32_t)(v & 1);
+    const uint32_t loc = (uint32_t)(h >> g.shard_bits) & ((1u << QH_WINDOW_BITS) - 1);
+    const uint64_t tag0 = (gsize >= 64 ? 0 : (h >> gsize)) << g.pbits;
+    uint32_t is_new = 0;
+    if (!qh_insert_lds(g, win, loc, tag0, q, &is_new)) {
+      const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(&meta->spill_count), 1ull);
+      if (at < spill_cap) spill[at] = v;
+      else meta->ovf_lost = 1;
+    }
+    n_new += is_new;
+  }
+  n_new = wave_sum_u32(n_new);
+  if ((tid & 63) == 0) wnew[tid >> 6] = n_new;
+  __syncthreads();
+  for (uint32_t i = tid; i < nvec; i += QP_THREADS) tw[i] = lw[i];
+  if (tid == 0) {
+    uint32_t t = 0;
+    for (int i = 0; i < QP_WAVES; ++i) t += wnew[i];
+    if (t) atomicAdd(reinterpret_cast<unsigned long long*>(&meta->new_keys), (unsigned long long)t);
+  }
+}
+
+void qh_launch_window_build(uint64_t* table, const qh_geom& g, const uint64_t* items, uint64_t cap,
+                            const unsigned long long* counts, uint32_t n_windows, int table_dirty, uint64_t* spill,
+                            uint64_t spill_cap, qh_meta* meta, hipStream_t s) {
+  hipLaunchKernelGGL(k_window_build, dim3(n_windows), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
+                     table_dirty, spill, spill_cap, meta);
+}

@@ -115,8 +115,8 @@ QH_HD uint64_t qh_table_slots(const qh_geom& g) {
   return 1ull << (g.lsize + (g.all_shards ? g.shard_bits : 0));
 }
 
-QH_HD qh_pos qh_locate(const qh_geom& g, uint64_t key) {
-  const uint64_t h = qh_mix(key, g.k);
+// position of a key given its hash h = qh_mix(key)
+QH_HD qh_pos qh_locate_hash(const qh_geom& g, uint64_t h) {
   const int gsize = g.lsize + g.shard_bits;
   qh_pos p;
   p.shard = (uint32_t)(h & qh_low_mask(g.shard_bits));
@@ -129,13 +129,15 @@ QH_HD qh_pos qh_locate(const qh_geom& g, uint64_t key) {
   return p;
 }
 
+QH_HD qh_pos qh_locate(const qh_geom& g, uint64_t key) { return qh_locate_hash(g, qh_mix(key, g.k)); }
+
 QH_HD uint64_t qh_probe_idx(const qh_geom& g, uint64_t home, uint32_t i) {
   const uint64_t wmask = qh_low_mask(g.wbits);
   return (home & ~wmask) | ((home + i) & wmask);
 }
 
-// key stored in the occupied slot word `slot` found at index `idx`
-QH_HD uint64_t qh_slot_key(const qh_geom& g, uint64_t slot, uint64_t idx) {
+// hash of the key stored in the occupied slot word `slot` found at index `idx`
+QH_HD uint64_t qh_slot_hash(const qh_geom& g, uint64_t slot, uint64_t idx) {
   const uint64_t wmask = qh_low_mask(g.wbits);
   const uint64_t f = slot >> g.vbits;
   const uint32_t i = (uint32_t)(f & qh_low_mask(g.pbits)) - 1;
@@ -145,7 +147,12 @@ QH_HD uint64_t qh_slot_key(const qh_geom& g, uint64_t slot, uint64_t idx) {
   const uint64_t shard = g.all_shards ? home >> g.lsize : (uint64_t)g.shard_id;
   uint64_t h = ((home & qh_low_mask(g.lsize)) << g.shard_bits) | shard;
   if (gsize < 64) h |= rem << gsize;
-  return qh_unmix(h & g.kmask, g.k);
+  return h & g.kmask;
+}
+
+// key stored in the occupied slot word `slot` found at index `idx`
+QH_HD uint64_t qh_slot_key(const qh_geom& g, uint64_t slot, uint64_t idx) {
+  return qh_unmix(qh_slot_hash(g, slot, idx), g.k);
 }
 
 // Quorum's update rule (src/mer_database.hpp:104-110) on a value field.

@@ -114,11 +114,18 @@ class HashWithQuality:
     def enable_timing(self, on=True):
         check(lib.qh_build_enable_timing(self._h, 1 if on else 0))
 
-    def kernel_time(self):
-        """(total ms, launches) of the dominant kernel since enable_timing()"""
+    KERNELS = ("k_build_direct/k_insert_items", "k_partition<FASTQ|ITEMS> level 1", "k_partition<ITEMS> level 2",
+               "k_window_build")
+
+    def kernel_time(self, which=0):
+        """(total ms, launches) of one of the main kernels since enable_timing():
+        0 direct build / insert, 1 partition level 1, 2 partition level 2, 3 window build"""
         ms, n = C.c_double(), C.c_uint64()
-        check(lib.qh_build_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        check(lib.qh_build_kernel_time(self._h, which, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def set_mode(self, mode="auto", level1_bits=-1):
+        check(lib.qh_build_set_mode(self._h, {"auto": 0, "direct": 1, "partition": 2}[mode], level1_bits))
 
     def reset(self):
         check(lib.qh_build_reset(self._h))

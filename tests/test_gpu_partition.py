@@ -1,0 +1,105 @@
+"""The radix-partitioned build (qh_partition.hip) against the oracle and against the
+direct global-CAS build: both strategies must give the same content on every input."""
+import numpy as np
+import pytest
+import torch
+
+import pyoracle as po
+import quorum_amd as qa
+from quorum_amd import synth
+from helpers import random_fastq, sorted_pairs, dict_model_np
+
+pytestmark = pytest.mark.gpu
+
+
+def build(data, k, bits, size, mode, level1_bits=-1, chunks=1, thresh=38, **kw):
+    h = qa.HashWithQuality(size, 2 * k, bits, min_qual=thresh, **kw)
+    h.set_mode(mode, level1_bits)
+    if chunks == 1:
+        h.add_fastq(data)
+    else:
+        recs = data.split(b"@read")[1:]
+        step = (len(recs) + chunks - 1) // chunks
+        for i in range(0, len(recs), step):
+            h.add_fastq(b"".join(b"@read" + r for r in recs[i:i + step]))
+    st = h.done()
+    m, v = sorted_pairs(*h.dump())
+    return h, st, m, v
+
+
+@pytest.mark.parametrize("size,level1_bits,chunks", [(1 << 14, -1, 1), (1 << 16, -1, 1), (1 << 20, -1, 3),
+                                                     (1 << 20, 3, 1), (1 << 22, 4, 2), (1 << 22, 0, 1)])
+@pytest.mark.parametrize("k,bits", [(24, 7), (31, 3), (9, 5)])
+def test_partitioned_matches_oracle(size, level1_bits, chunks, k, bits):
+    rng = np.random.default_rng(size % 1000 + k)
+    data = random_fastq(rng, 5000, k=k, genome=rng.integers(0, 4, size=30000))
+    db = po.OracleDB(1 << 22, k, bits)
+    n = db.add_fastq(data, 38, threads=4)
+    om, ov = db.sorted_dump()
+    h, st, m, v = build(data, k, bits, size, "partition", level1_bits, chunks)
+    assert st["instances"] == n and st["records"] == 5000 and st["distinct"] == om.size
+    assert m.size == om.size and (m == om).all() and (v == ov).all()
+    h2, st2, m2, v2 = build(data, k, bits, size, "direct")
+    assert (m2 == om).all() and (v2 == ov).all()
+
+
+def test_partitioned_growth_and_contention():
+    """a 16384-slot table receiving far more distinct k-mers than it holds: windows overflow, the
+    spill list is inserted directly, the table doubles; plus a poly-A read (one slot, 5000 updates)"""
+    rng = np.random.default_rng(77)
+    data = random_fastq(rng, 6000, k=21, genome=rng.integers(0, 4, size=200000))
+    data += b"@readpoly\n" + b"A" * 5000 + b"\n+\n" + b"I" * 5000 + b"\n"
+    db = po.OracleDB(1 << 22, 21, 7)
+    n = db.add_fastq(data, 38, threads=4)
+    om, ov = db.sorted_dump()
+    assert om.size > 4 * (1 << 14)
+    h, st, m, v = build(data, 21, 7, 1 << 14, "partition", chunks=2)
+    assert st["instances"] == n and st["grows"] >= 2
+    assert (m == om).all() and (v == ov).all()
+
+
+def test_partitioned_add_mers_and_sharded():
+    rng = np.random.default_rng(5)
+    k, bits = 16, 4
+    mers = rng.integers(0, 4 ** k, size=300000, dtype=np.uint64)
+    mers[::2] = mers[1::2]
+    hq = (rng.random(mers.size) < 0.5).astype(np.uint8)
+    um, uv = dict_model_np(mers, hq, bits)
+    h = qa.HashWithQuality(1 << 18, 2 * k, bits)
+    h.set_mode("partition")
+    assert h.add(mers, hq)
+    m, v = sorted_pairs(*h.dump())
+    assert (m == um).all() and (v == uv).all()
+    # sharded handles in partition mode keep exactly their own keys
+    parts = []
+    for s in range(4):
+        hs = qa.HashWithQuality(1 << 18, 2 * k, bits, shard_bits=2, shard_id=s)
+        hs.set_mode("partition")
+        assert hs.add(mers, hq)
+        st = hs.done()
+        assert st["instances"] + st["foreign"] == mers.size
+        parts.append(hs.dump())
+    m = np.concatenate([p[0] for p in parts])
+    v = np.concatenate([p[1] for p in parts])
+    assert np.unique(m).size == m.size
+    m, v = sorted_pairs(m, v)
+    assert (m == um).all() and (v == uv).all()
+
+
+def test_modes_agree_at_full_size():
+    """BASELINE config 2 at full size: direct and partitioned builds give the identical table"""
+    k, bits, thresh = 24, 7, 38
+    g = synth.make_genome(5_000_000)
+    fq = synth.make_fastq(g, 2_000_000, 100)
+    chunk = torch.from_numpy(fq).to("cuda:0")
+    dumps = []
+    for mode in ("direct", "partition"):
+        h = qa.HashWithQuality(50_000_000, 2 * k, bits, min_qual=thresh)
+        h.set_mode(mode)
+        h.add_fastq_device(chunk.data_ptr(), chunk.numel())
+        st = h.done()
+        dumps.append((st, sorted_pairs(*h.dump())))
+        h.close()
+    (s0, (m0, v0)), (s1, (m1, v1)) = dumps
+    assert s0["instances"] == s1["instances"] and s0["distinct"] == s1["distinct"] == m0.size
+    assert (m0 == m1).all() and (v0 == v1).all()

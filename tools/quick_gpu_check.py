@@ -16,6 +16,8 @@ db = po.OracleDB(1 << 22, k, bits)
 n = db.add_fastq(fq, thresh, threads=8)
 print("oracle: %d instances, %d distinct, %.2fs" % (n, db.distinct(), time.time() - t), flush=True)
 h = qa.HashWithQuality(1 << 22, 2 * k, bits, min_qual=thresh)
+if len(sys.argv) > 2:
+    h.set_mode(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else -1)
 t = time.time()
 h.add_fastq(fq)
 st = h.done()
