@@ -138,7 +138,7 @@ extern "C" void qh_build_destroy(qh_build* h) {
   if (!h) return;
   hipError_t e = hipSetDevice(h->device); (void)e;
   if (h->stream) { e = hipStreamSynchronize(h->stream); (void)e; }
-  void* ptrs[] = {h->table, h->d_meta, h->d_chunk, h->d_recs, h->d_tiles, h->d_ovf[0], h->d_ovf[1], h->d_items, h->d_shard_counts, h->d_blkprefix, h->d_rbsums,
+  void* ptrs[] = {h->table, h->d_meta, h->d_chunk, h->d_recs, h->d_tiles, h->d_ovf[0], h->d_ovf[1], h->d_items, h->d_shard_counts, h->d_blkprefix, h->d_rbsums, h->d_blkrec,
                   h->d_bins[0], h->d_bins[1], h->d_bin_counts[0], h->d_bin_counts[1]};
   for (void* p : ptrs) if (p) { e = hipFree(p); (void)e; }
   if (h->h_meta) { e = hipHostFree(h->h_meta); (void)e; }
@@ -317,6 +317,7 @@ static bool use_partition(const qh_build* h, size_t max_items) {
 struct part_source {
   const uint8_t* fastq = nullptr;    // FASTQ chunk whose record table is in h->d_recs
   size_t rec_cap = 0;
+  size_t max_blocks = 0;             // upper bound of the chunk's 64-base blocks
   const uint64_t* items = nullptr;   // or an item list
   size_t n_items = 0;
   int hashed = 0;
@@ -357,8 +358,9 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
   if (src.fastq) {
     if ((rc = ensure((void**)&h->d_rbsums, &h->rbsums_cap, (src.rec_cap / 1024 + 4) * 4, "record block sums"))) return rc;
     if ((rc = ensure((void**)&h->d_blkprefix, &h->blkprefix_cap, (src.rec_cap + 2) * 4, "record block prefix"))) return rc;
-    qh_launch_rec_blocks(h->d_recs, (uint32_t)src.rec_cap, h->d_meta, h->d_rbsums, h->d_blkprefix, h->stream);
-    qh_launch_partition_fastq(src.fastq, h->d_recs, h->d_blkprefix, h->d_meta, g, l1_dst, check_owner, h->stream);
+    if ((rc = ensure((void**)&h->d_blkrec, &h->blkrec_cap, (src.max_blocks + 2) * 4, "block records"))) return rc;
+    qh_launch_rec_blocks(h->d_recs, (uint32_t)src.rec_cap, h->d_meta, h->d_rbsums, h->d_blkprefix, h->d_blkrec, h->stream);
+    qh_launch_partition_fastq(src.fastq, h->d_recs, h->d_blkprefix, h->d_blkrec, h->d_meta, g, l1_dst, check_owner, h->stream);
   } else {
     qh_launch_partition_items(src.items, src.n_items, nullptr, 1, src.n_items, src.hashed, h->d_meta, g, l1_dst,
                               check_owner, 1, h->stream);
@@ -400,6 +402,7 @@ extern "C" int qh_build_add_fastq_device(qh_build* h, const void* dev_buf, size_
     part_source src;
     src.fastq = (const uint8_t*)dev_buf;
     src.rec_cap = rec_cap;
+    src.max_blocks = len / 64 + rec_cap;
     if ((rc = run_partitioned(h, src, len / 2))) return rc;
   } else {
     timing_begin(h);
@@ -450,6 +453,7 @@ static int submit_records(qh_build* h, const uint8_t* dev_buf, const qh_record* 
     part_source src;
     src.fastq = dev_buf;
     src.rec_cap = nrec;
+    src.max_blocks = max_items / 64 + nrec;
     if ((rc = run_partitioned(h, src, max_items))) return rc;
   } else {
     timing_begin(h);

@@ -18,6 +18,7 @@
 //   k_window_build     bucket -> LDS window -> table
 #include "qh_kernels.h"
 #include "qh_device.h"
+#include <stdlib.h>
 
 #define QP_THREADS 1024
 #define QP_WAVES (QP_THREADS / 64)
@@ -71,7 +72,8 @@ __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t* __restrict__ v, uin
 __global__ __launch_bounds__(256) void k_rec_blocks_apply(const uint4* __restrict__ recs, const qh_meta* __restrict__ meta,
                                                           const uint32_t* __restrict__ tile_prefix,
                                                           const uint32_t* __restrict__ total,
-                                                          uint32_t* __restrict__ blk_prefix) {
+                                                          uint32_t* __restrict__ blk_prefix,
+                                                          uint32_t* __restrict__ blk_rec) {
   __shared__ uint32_t wtot[4];
   const uint32_t nrec = meta->format_err ? 0 : meta->nrec;
   const uint32_t base = blockIdx.x * RB_TILE;
@@ -99,7 +101,11 @@ __global__ __launch_bounds__(256) void k_rec_blocks_apply(const uint4* __restric
       if (w < wv) wbase += x;
       tot += x;
     }
-    if (r < nrec) blk_prefix[r] = run + wbase + inc - c;
+    if (r < nrec) {
+      const uint32_t pb = run + wbase + inc - c;
+      blk_prefix[r] = pb;
+      for (uint32_t b = 0; b < c; ++b) blk_rec[pb + b] = r;  // record of every 64-base block
+    }
     run += tot;
     __syncthreads();
   }
@@ -107,12 +113,12 @@ __global__ __launch_bounds__(256) void k_rec_blocks_apply(const uint4* __restric
 }
 
 void qh_launch_rec_blocks(const uint4* recs, uint32_t rec_cap, const qh_meta* meta, uint32_t* tile_sums,
-                          uint32_t* blk_prefix, hipStream_t s) {
+                          uint32_t* blk_prefix, uint32_t* blk_rec, hipStream_t s) {
   const uint32_t ntiles = (rec_cap + RB_TILE - 1) / RB_TILE;
   // tile_sums[ntiles] receives the total
   hipLaunchKernelGGL(k_rec_blocks_sum, dim3(ntiles), dim3(256), 0, s, recs, meta, tile_sums);
   hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, tile_sums, ntiles, tile_sums + ntiles);
-  hipLaunchKernelGGL(k_rec_blocks_apply, dim3(ntiles), dim3(256), 0, s, recs, meta, tile_sums, tile_sums + ntiles, blk_prefix);
+  hipLaunchKernelGGL(k_rec_blocks_apply, dim3(ntiles), dim3(256), 0, s, recs, meta, tile_sums, tile_sums + ntiles, blk_prefix, blk_rec);
 }
 
 // ------------------------------------------------------------- LDS-staged multi-split
@@ -134,12 +140,14 @@ struct qp_params {
   const uint8_t* buf;
   const uint4* recs;
   const uint32_t* blk_prefix;
+  const uint32_t* blk_rec;
   // SRC_ITEMS: input bucket b = blockIdx.y holds in[b * in_cap ...], in_counts[b] items (or in_n when in_counts == 0)
   const uint64_t* in;
   uint64_t in_cap;
   const unsigned long long* in_counts;
   uint64_t in_n;
   int in_hashed;       // 0: (mer<<1|q) as the C ABI passes them, 1: (hash<<1|q)
+  int ablate;          // timing experiments only (QH_ABLATE): 16 no write-out, 32 no placement, 64 no histogram
 };
 
 enum { QP_SRC_FASTQ = 0, QP_SRC_ITEMS = 1 };
@@ -191,50 +199,62 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
     for (int i = 0; i < QP_BLOCKS_PER_WAVE; ++i) it[i] = QP_NONE;
 
     if (SRC == QP_SRC_FASTQ) {
+      // The wave owns blocks g0 .. g0+11. Lane s < 13 resolves block g0-1+s (slot 0 is the block
+      // before the first one: the window of a k-mer reaches k-1 bases back) to its record, then
+      // the bytes of all 13 blocks are requested before any of them is used.
       const uint32_t g0 = (uint32_t)tile * QP_TILE_BLOCKS + wave * QP_BLOCKS_PER_WAVE;
-      if (g0 < nblk) {
-        // record of block g0: the largest r with blk_prefix[r] <= g0
-        uint32_t lo = 0, hi = nrec;  // invariant: blk_prefix[lo] <= g0 < blk_prefix[hi]
-        while (hi - lo > 1) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (p.blk_prefix[mid] <= g0) lo = mid; else hi = mid;
+      uint32_t d_so = 0, d_qo = 0, d_n = 0, d_r = 0xFFFFFFFFu;
+      {
+        const uint32_t gb = g0 + lane - 1;
+        if (lane <= QP_BLOCKS_PER_WAVE && (lane > 0 || g0 > 0) && gb < nblk) {
+          const uint32_t r = p.blk_rec[gb];
+          const uint4 rc = p.recs[r];
+          const uint32_t off = (gb - p.blk_prefix[r]) * 64;
+          d_so = rc.x + off; d_qo = rc.z + off; d_r = r;
+          d_n = rc.y - off < 64 ? rc.y - off : 64;
         }
-        uint32_t r = __builtin_amdgcn_readfirstlane(lo);
-        uint4 rc = p.recs[r];
-        uint32_t rbeg = p.blk_prefix[r], rend = p.blk_prefix[r + 1];
-        qh_planes prev = {0, 0, 0, 0};
-        bool have_prev = false;
+      }
+      // unconditional loads (lanes past the block's end re-read its first byte and are masked when
+      // the planes are formed): no branch around a load, so all 26 are in flight together
+      uint8_t bb[QP_BLOCKS_PER_WAVE + 1];
+      int8_t qq[QP_BLOCKS_PER_WAVE + 1];
 #pragma unroll
-        for (int i = 0; i < QP_BLOCKS_PER_WAVE; ++i) {
-          const uint32_t gb = g0 + i;
-          if (gb < nblk) {
-            while (gb >= rend) {  // next record (records without blocks are skipped)
-              ++r;
-              rc = p.recs[r];
-              rbeg = rend;
-              rend = p.blk_prefix[r + 1];
-              have_prev = false;
+      for (int sl = 0; sl <= QP_BLOCKS_PER_WAVE; ++sl) {
+        const uint32_t so = __builtin_amdgcn_readlane(d_so, sl), qo = __builtin_amdgcn_readlane(d_qo, sl);
+        const uint32_t nv = __builtin_amdgcn_readlane(d_n, sl);
+        const uint32_t l = (uint32_t)lane < nv ? (uint32_t)lane : 0u;
+        bb[sl] = p.buf[(size_t)so + l];
+        qq[sl] = (int8_t)p.buf[(size_t)qo + l];
+      }
+      qh_planes prev = {0, 0, 0, 0};
+      uint32_t prev_r = 0xFFFFFFFFu;
+#pragma unroll
+      for (int sl = 0; sl <= QP_BLOCKS_PER_WAVE; ++sl) {
+        const uint32_t r = __builtin_amdgcn_readlane(d_r, sl);
+        const int code = qh_code(bb[sl]);
+        const bool valid = code >= 0 && (uint32_t)lane < (uint32_t)__builtin_amdgcn_readlane(d_n, sl);
+        qh_planes cur;
+        cur.v = __ballot(valid);
+        cur.h = __ballot(valid && (int)qq[sl] >= (int)(int8_t)g.min_qual);
+        cur.l0 = __ballot(valid && (code & 1));
+        cur.l1 = __ballot(valid && (code & 2));
+        if (sl > 0 && r != 0xFFFFFFFFu) {
+          if (r != prev_r) prev = qh_planes{0, 0, 0, 0};  // first block of its record
+          uint64_t key;
+          uint32_t q;
+          if (qh_lane_kmer(cur, prev, lane, g.k, &key, &q)) {
+            const uint64_t h = qh_mix(key, g.k);
+            if (p.check_owner && ((uint32_t)h & smask) != (uint32_t)g.shard_id) {
+              ++n_foreign;
+            } else {
+              ++n_inst; n_hq += q;
+              it[sl - 1] = (h << 1) | q;
+              if (!(p.ablate & 64)) atomicAdd(&cursor[(uint32_t)(h >> p.bin_shift) & p.bin_mask], 1u);
             }
-            const uint32_t j = gb - rbeg;
-            if (j == 0) prev = qh_planes{0, 0, 0, 0};
-            else if (!have_prev) prev = qh_load_planes(p.buf, rc.x, rc.z, rc.y, (j - 1) * 64, lane, g.min_qual);
-            const qh_planes cur = qh_load_planes(p.buf, rc.x, rc.z, rc.y, j * 64, lane, g.min_qual);
-            uint64_t key;
-            uint32_t q;
-            if (qh_lane_kmer(cur, prev, lane, g.k, &key, &q)) {
-              const uint64_t h = qh_mix(key, g.k);
-              if (p.check_owner && ((uint32_t)h & smask) != (uint32_t)g.shard_id) {
-                ++n_foreign;
-              } else {
-                ++n_inst; n_hq += q;
-                it[i] = (h << 1) | q;
-                atomicAdd(&cursor[(uint32_t)(h >> p.bin_shift) & p.bin_mask], 1u);
-              }
-            }
-            prev = cur;
-            have_prev = true;
           }
         }
+        prev = cur;
+        prev_r = r;
       }
     } else {
       const uint64_t j0 = tile * QP_TILE_ITEMS + (uint64_t)wave * (QP_BLOCKS_PER_WAVE * 64) + lane;
@@ -301,7 +321,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
     // ---- pass 2: place the items bucket-sorted into LDS
 #pragma unroll
     for (int i = 0; i < QP_BLOCKS_PER_WAVE; ++i) {
-      if (it[i] != QP_NONE) {
+      if (it[i] != QP_NONE && !(p.ablate & 32)) {
         const uint32_t b = (uint32_t)((it[i] >> 1) >> p.bin_shift) & p.bin_mask;
         sorted[atomicAdd(&cursor[b], 1u)] = it[i];
       }
@@ -309,7 +329,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
     __syncthreads();
 
     // ---- stream the tile out: consecutive lanes of one bucket write consecutive words
-    const uint32_t total = s_total;
+    const uint32_t total = (p.ablate & 16) ? 0 : s_total;
     for (uint32_t j = tid; j < total; j += QP_THREADS) {
       const uint64_t v = sorted[j];
       const uint32_t b = (uint32_t)((v >> 1) >> p.bin_shift) & p.bin_mask;
@@ -335,13 +355,16 @@ static void fill_common(qp_params& p, const qh_part_dst& d, qh_meta* meta, int c
   p.bin_shift = d.bin_shift; p.bin_mask = (1u << d.bin_bits) - 1; p.out_bin_shift = d.out_bin_shift;
   p.spill = d.spill; p.spill_cap = d.spill_cap; p.meta = meta;
   p.check_owner = check_owner; p.count_instances = count_instances;
+  static const int ablate = getenv("QH_ABLATE") ? atoi(getenv("QH_ABLATE")) : 0;
+  p.ablate = ablate;
 }
 
-void qh_launch_partition_fastq(const uint8_t* buf, const uint4* recs, const uint32_t* blk_prefix, qh_meta* meta,
+void qh_launch_partition_fastq(const uint8_t* buf, const uint4* recs, const uint32_t* blk_prefix,
+                               const uint32_t* blk_rec, qh_meta* meta,
                                const qh_geom& g, const qh_part_dst& d, int check_owner, hipStream_t s) {
   qp_params p = {};
   fill_common(p, d, meta, check_owner, 1);
-  p.buf = buf; p.recs = recs; p.blk_prefix = blk_prefix;
+  p.buf = buf; p.recs = recs; p.blk_prefix = blk_prefix; p.blk_rec = blk_rec;
   hipLaunchKernelGGL(k_partition<QP_SRC_FASTQ>, dim3(256), dim3(QP_THREADS), 0, s, p, g);
 }
 
@@ -363,15 +386,16 @@ void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsign
 // ----------------------------------------------------------------- window build
 
 // hash_with_quality::add on a window held in LDS (same slot format and probe rule as
-// qh_insert, local index instead of a global one)
+// qh_insert, local index instead of a global one). `old` is the caller's (possibly
+// stale) read of probe 0: every decision taken on it is re-validated by the CAS.
 __device__ __forceinline__ bool qh_insert_lds(const qh_geom& g, uint64_t* win, uint32_t loc, uint64_t tag0,
-                                              uint32_t q, uint32_t* is_new) {
+                                              uint32_t q, uint64_t old, uint32_t* is_new) {
   const uint32_t wmask = (1u << QH_WINDOW_BITS) - 1;
   const uint64_t fresh = q ? 3u : 2u;
   for (uint32_t i = 0; i <= (uint32_t)g.max_reprobe; ++i) {
     unsigned long long* slot = reinterpret_cast<unsigned long long*>(win + ((loc + i) & wmask));
     const uint64_t want = tag0 | (i + 1);
-    uint64_t old = *reinterpret_cast<volatile unsigned long long*>(slot);
+    if (i) old = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     for (;;) {
       if (old == 0) {
         const uint64_t prev = atomicCAS(slot, 0ull, (unsigned long long)((want << g.vbits) | fresh));
@@ -389,11 +413,14 @@ __device__ __forceinline__ bool qh_insert_lds(const qh_geom& g, uint64_t* win, u
   return false;
 }
 
+#define QW_UNROLL 4
+
 __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restrict__ table, const qh_geom g,
                                                              const uint64_t* __restrict__ items, uint64_t cap,
                                                              const unsigned long long* __restrict__ counts,
                                                              int table_dirty, uint64_t* __restrict__ spill,
-                                                             uint64_t spill_cap, qh_meta* __restrict__ meta) {
+                                                             uint64_t spill_cap, qh_meta* __restrict__ meta,
+                                                             int ablate) {
   __shared__ uint64_t win[1u << QH_WINDOW_BITS];
   __shared__ uint32_t wnew[QP_WAVES];
   const uint32_t w = blockIdx.x;
@@ -401,36 +428,67 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
   if (n > cap) n = cap;
   if (n == 0) return;  // nothing to add: the window stays as it is
   const int tid = threadIdx.x;
+  const uint64_t* src = items + (uint64_t)w * cap;
+  // first batch of items in flight while the window is brought into LDS
+  uint64_t nxt[QW_UNROLL];
+#pragma unroll
+  for (int u = 0; u < QW_UNROLL; ++u) {
+    const uint64_t j = (uint64_t)u * QP_THREADS + tid;
+    nxt[u] = j < n ? src[j] : QP_NONE;
+  }
   uint4* tw = reinterpret_cast<uint4*>(table + ((uint64_t)w << QH_WINDOW_BITS));
   uint4* lw = reinterpret_cast<uint4*>(win);
   const uint32_t nvec = (1u << QH_WINDOW_BITS) / 2;  // 16-byte pieces
   if (table_dirty) {
-    for (uint32_t i = tid; i < nvec; i += QP_THREADS) lw[i] = tw[i];
+#pragma unroll
+    for (uint32_t i = 0; i < nvec / QP_THREADS; ++i) lw[i * QP_THREADS + tid] = tw[i * QP_THREADS + tid];
   } else {
-    for (uint32_t i = tid; i < nvec; i += QP_THREADS) lw[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (uint32_t i = 0; i < nvec / QP_THREADS; ++i) lw[i * QP_THREADS + tid] = make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
-  const uint64_t* src = items + (uint64_t)w * cap;
   const int gsize = g.lsize + g.shard_bits;
+  const uint32_t wmask = (1u << QH_WINDOW_BITS) - 1;
   uint32_t n_new = 0;
-  for (uint64_t j = tid; j < n; j += QP_THREADS) {
-    const uint64_t v = src[j];
-    const uint64_t h = v >> 1;
-    const uint32_t q = (uint32_t)(v & 1);
-    const uint32_t loc = (uint32_t)(h >> g.shard_bits) & ((1u << QH_WINDOW_BITS) - 1);
-    const uint64_t tag0 = (gsize >= 64 ? 0 : (h >> gsize)) << g.pbits;
-    uint32_t is_new = 0;
-    if (!qh_insert_lds(g, win, loc, tag0, q, &is_new)) {
-      const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(&meta->spill_count), 1ull);
-      if (at < spill_cap) spill[at] = v;
-      else meta->ovf_lost = 1;
+  for (uint64_t base = 0; base < n; base += (uint64_t)QW_UNROLL * QP_THREADS) {
+    uint64_t v[QW_UNROLL], old[QW_UNROLL];
+#pragma unroll
+    for (int u = 0; u < QW_UNROLL; ++u) v[u] = nxt[u];
+    // next batch's loads are issued before this batch's LDS work
+#pragma unroll
+    for (int u = 0; u < QW_UNROLL; ++u) {
+      const uint64_t j = base + (uint64_t)(QW_UNROLL + u) * QP_THREADS + tid;
+      nxt[u] = j < n ? src[j] : QP_NONE;
     }
-    n_new += is_new;
+#pragma unroll
+    for (int u = 0; u < QW_UNROLL; ++u) {
+      const uint32_t loc = (uint32_t)((v[u] >> 1) >> g.shard_bits) & wmask;
+      old[u] = v[u] != QP_NONE ? __hip_atomic_load(&win[loc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < QW_UNROLL; ++u) {
+      if (v[u] == QP_NONE) continue;
+      const uint64_t h = v[u] >> 1;
+      const uint32_t q = (uint32_t)(v[u] & 1);
+      const uint32_t loc = (uint32_t)(h >> g.shard_bits) & wmask;
+      const uint64_t tag0 = (gsize >= 64 ? 0 : (h >> gsize)) << g.pbits;
+      uint32_t is_new = 0;
+      if (ablate & 1) { n_new += (uint32_t)(old[u] + tag0); continue; }  // timing-only build (QH_ABLATE)
+      if (!qh_insert_lds(g, win, loc, tag0, q, old[u], &is_new)) {
+        const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(&meta->spill_count), 1ull);
+        if (at < spill_cap) spill[at] = v[u];
+        else meta->ovf_lost = 1;
+      }
+      n_new += is_new;
+    }
   }
   n_new = wave_sum_u32(n_new);
   if ((tid & 63) == 0) wnew[tid >> 6] = n_new;
   __syncthreads();
-  for (uint32_t i = tid; i < nvec; i += QP_THREADS) tw[i] = lw[i];
+  if (!(ablate & 2)) {
+#pragma unroll
+    for (uint32_t i = 0; i < nvec / QP_THREADS; ++i) tw[i * QP_THREADS + tid] = lw[i * QP_THREADS + tid];
+  }
   if (tid == 0) {
     uint32_t t = 0;
     for (int i = 0; i < QP_WAVES; ++i) t += wnew[i];
@@ -441,6 +499,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
 void qh_launch_window_build(uint64_t* table, const qh_geom& g, const uint64_t* items, uint64_t cap,
                             const unsigned long long* counts, uint32_t n_windows, int table_dirty, uint64_t* spill,
                             uint64_t spill_cap, qh_meta* meta, hipStream_t s) {
+  static const int ablate = getenv("QH_ABLATE") ? atoi(getenv("QH_ABLATE")) : 0;  // timing experiments only
   hipLaunchKernelGGL(k_window_build, dim3(n_windows), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
-                     table_dirty, spill, spill_cap, meta);
+                     table_dirty, spill, spill_cap, meta, ablate);
 }
