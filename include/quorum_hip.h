@@ -111,6 +111,8 @@ int qh_build_add_records_device(qh_build* h, const void* dev_buf, size_t len,
  * _device takes packed items  mer << 1 | quality  in device memory. */
 int qh_build_add_mers(qh_build* h, const uint64_t* mers, const uint8_t* quality, size_t n);
 int qh_build_add_mers_device(qh_build* h, const uint64_t* dev_items, size_t n);
+/* same for items produced by qh_build_extract_partitioned_device (hashed form) */
+int qh_build_add_hashed_device(qh_build* h, const uint64_t* dev_items, size_t n);
 
 /* Waits for queued work, performs table doubling when a chunk overflowed
  * (the role of handle_full_ary, src/mer_database.hpp:137-187) and returns the
@@ -152,9 +154,12 @@ int qh_build_dump(qh_build* h, uint64_t* mers, uint64_t* vals, uint64_t cap, uin
 int qh_build_as_query(qh_build* h, qh_query** out);
 
 /* Multi-GPU exchange support (no upstream counterpart).  Extracts the
- * chunk's (canonical mer, hq) items, packed mer << 1 | hq, bucketed by owner
- * shard: items for shard s are written to dev_out[s*cap_per_shard ...] and their
- * number to dev_counts[s] (uint64, device memory, zeroed by the call). */
+ * chunk's (canonical mer, hq) items bucketed by owner shard: items for shard s are
+ * written to dev_out[s*cap_per_shard ...] and their number to dev_counts[s]
+ * (uint64, device memory, zeroed by the call).  Items are in the library's hashed
+ * form  hash(mer) << 1 | hq  (the hash is a bijection of the mer; owner = its low
+ * shard_bits): opaque 8-byte words to be exchanged and handed to
+ * qh_build_add_hashed_device on the owning shard. */
 int qh_build_extract_partitioned_device(qh_build* h, const void* dev_buf, size_t len,
                                         uint64_t* dev_out, uint64_t cap_per_shard,
                                         uint64_t* dev_counts);
@@ -241,6 +246,12 @@ int qh_build_set_mode(qh_build* h, int mode, int level1_bits);
  * milliseconds through *ms. */
 int qh_bench_random_access(int device, int lsize, uint64_t n_updates, int mode, int iters,
                            double* ms);
+
+/* LDS operation-rate microbenchmark (design input for the LDS window build): lane
+ * operations per second chip-wide for mode 0 ds_read_b64, 1 ds_write_b64,
+ * 2 ds_cmpst_rtn_b64, 3 ds_cmpst_rtn_b32, 4 ds_add_rtn_u32, 5 ds_add_u32,
+ * 6 ds_add_rtn_u64, 7 read+write+read of one slot. */
+int qh_bench_lds_rate(int device, int mode, int iters, double* lane_ops_per_s);
 
 #ifdef __cplusplus
 }

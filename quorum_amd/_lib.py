@@ -53,6 +53,7 @@ SIGNATURES = [
     ("qh_build_add_records_device", C.c_int, [_p, _p, C.c_size_t, C.POINTER(QhRecord), C.c_size_t]),
     ("qh_build_add_mers", C.c_int, [_p, _u64p, _u8p, C.c_size_t]),
     ("qh_build_add_mers_device", C.c_int, [_p, _p, C.c_size_t]),
+    ("qh_build_add_hashed_device", C.c_int, [_p, _p, C.c_size_t]),
     ("qh_build_sync", C.c_int, [_p]),
     ("qh_build_finish", C.c_int, [_p, C.POINTER(QhBuildStats)]),
     ("qh_build_get_stats", C.c_int, [_p, C.POINTER(QhBuildStats)]),
@@ -78,6 +79,7 @@ SIGNATURES = [
     ("qh_build_enable_timing", C.c_int, [_p, C.c_int]),
     ("qh_build_kernel_time", C.c_int, [_p, C.c_int, C.POINTER(C.c_double), _u64p]),
     ("qh_build_set_mode", C.c_int, [_p, C.c_int, C.c_int]),
+    ("qh_bench_lds_rate", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("qh_bench_random_access", C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 ]
 

@@ -584,7 +584,17 @@ extern "C" int qh_build_add_fastq_host_parsed(qh_build* h, const char* buf, size
   return submit_records(h, h->d_chunk, recs.data(), recs.size(), total);
 }
 
+static int add_items_device(qh_build* h, const uint64_t* dev_items, size_t n, int hashed);
+
 extern "C" int qh_build_add_mers_device(qh_build* h, const uint64_t* dev_items, size_t n) {
+  return add_items_device(h, dev_items, n, 0);
+}
+
+extern "C" int qh_build_add_hashed_device(qh_build* h, const uint64_t* dev_items, size_t n) {
+  return add_items_device(h, dev_items, n, 1);
+}
+
+static int add_items_device(qh_build* h, const uint64_t* dev_items, size_t n, int hashed) {
   if (!h) return qh_fail(QH_EBADARG, "null handle");
   if (n == 0) return QH_OK;
   if (!dev_items) return qh_fail(QH_EBADARG, "null items");
@@ -594,11 +604,11 @@ extern "C" int qh_build_add_mers_device(qh_build* h, const uint64_t* dev_items, 
     part_source src;
     src.items = dev_items;
     src.n_items = n;
-    src.hashed = 0;
+    src.hashed = hashed;
     if ((rc = run_partitioned(h, src, n))) return rc;
   } else {
     timing_begin(h);
-    qh_launch_insert_items(dev_items, n, nullptr, 1, 0, h->d_meta, h->g, h->table, h->d_ovf[h->cur_ovf], h->ovf_cap[h->cur_ovf] / 8, h->stream);
+    qh_launch_insert_items(dev_items, n, nullptr, 1, hashed, h->d_meta, h->g, h->table, h->d_ovf[h->cur_ovf], h->ovf_cap[h->cur_ovf] / 8, h->stream);
     timing_end(h);
   }
   h->table_dirty = true;
@@ -642,8 +652,16 @@ extern "C" int qh_build_extract_partitioned_device(qh_build* h, const void* dev_
   if ((rc = ensure((void**)&h->d_tiles, &h->tile_cap, (ntiles + 1) * 4, "tile counts"))) return rc;
   if ((rc = ensure((void**)&h->d_recs, &h->rec_cap, rec_cap * 16, "record table"))) return rc;
   qh_launch_index_fastq((const uint8_t*)dev_buf, len, h->d_tiles, h->d_recs, (uint32_t)rec_cap, h->d_meta, h->stream);
-  qh_launch_extract_partitioned((const uint8_t*)dev_buf, h->d_recs, h->d_meta, h->g, dev_out, cap_per_shard,
-                                (unsigned long long*)dev_counts, h->stream);
+  const size_t max_blocks = len / 64 + rec_cap;
+  if ((rc = ensure((void**)&h->d_rbsums, &h->rbsums_cap, (rec_cap / 1024 + 4) * 4, "record block sums"))) return rc;
+  if ((rc = ensure((void**)&h->d_blkprefix, &h->blkprefix_cap, (rec_cap + 2) * 4, "record block prefix"))) return rc;
+  if ((rc = ensure((void**)&h->d_blkrec, &h->blkrec_cap, (max_blocks + 2) * 4, "block records"))) return rc;
+  qh_launch_rec_blocks(h->d_recs, (uint32_t)rec_cap, h->d_meta, h->d_rbsums, h->d_blkprefix, h->d_blkrec, h->stream);
+  // bucket = owner shard = low shard_bits of the hash; a bucket that overflows is an error here
+  qh_part_dst dst = {dev_out, cap_per_shard, (unsigned long long*)dev_counts, 0, h->g.shard_bits, 0, nullptr, 0};
+  timing_begin(h, 1);
+  qh_launch_partition_fastq((const uint8_t*)dev_buf, h->d_recs, h->d_blkprefix, h->d_blkrec, h->d_meta, h->g, dst, 0, h->stream);
+  timing_end(h, 1);
   QH_HIP(hipGetLastError());
   // format / capacity verdict of this call
   QH_HIP(hipMemcpyAsync(h->h_meta, h->d_meta, sizeof(qh_meta), hipMemcpyDeviceToHost, h->stream));

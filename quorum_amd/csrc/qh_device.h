@@ -5,7 +5,7 @@
 // rolling canonical k-mer extraction of src/create_database.cc:64-92.
 //
 // Internal item format everywhere below the C ABI: (h << 1) | q with
-// h = qh_mix(canonical mer) -- the hash is a bijection of the 2k-bit key, so
+// h = qh_mix(qh_pkey(canonical mer)) -- the hash is a bijection of the 2k-bit key, so
 // nothing is lost and no kernel after extraction recomputes it.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -85,17 +85,6 @@ __device__ __forceinline__ void qh_overflow(qh_meta* __restrict__ meta, uint64_t
   else meta->ovf_lost = 1;
 }
 
-// 32 plane bits -> even bit positions of a 64-bit word
-__device__ __forceinline__ uint64_t spread32(uint32_t v) {
-  uint64_t x = v;
-  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
-  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
-  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
-  x = (x | (x << 2)) & 0x3333333333333333ull;
-  x = (x | (x << 1)) & 0x5555555555555555ull;
-  return x;
-}
-
 // Wave-parallel form of create_database.cc:64-92 for one 64-base column block of
 // one read. Each lane owns one base; the wave's four ballots are the bit planes
 // (valid, high-quality, code bit 0, code bit 1) of 64 consecutive positions, and
@@ -105,26 +94,36 @@ __device__ __forceinline__ uint64_t spread32(uint32_t v) {
 // scalar loop never need clearing because only complete windows are emitted.
 struct qh_planes { uint64_t v, h, l0, l1; };
 
-__device__ __forceinline__ uint64_t window_top(uint64_t cur, uint64_t prev, int lane) {
-  // bit 63 = this lane's position, bit 63-i = i positions earlier
-  return (cur << (63 - lane)) | ((prev >> lane) >> 1);
+// the 32 positions ending at this lane's base: bit 31 = the lane's position, bit 31-i = i earlier
+__device__ __forceinline__ uint32_t window_top32(uint64_t cur, uint64_t prev, int lane) {
+  return (uint32_t)(((cur << (63 - lane)) | ((prev >> lane) >> 1)) >> 32);
 }
 
+// Emits the canonical k-mer ending at this lane's base as a PLANE KEY (qh_pkey form: low code
+// bits | high code bits << k); the 2-bit interleaved form is never built on this path.
 __device__ __forceinline__ bool qh_lane_kmer(const qh_planes& cur, const qh_planes& prev, int lane, int k,
-                                             uint64_t* key, uint32_t* hq) {
-  const uint64_t kones = (1ull << k) - 1;
-  const int drop = 64 - k;
-  if ((window_top(cur.v, prev.v, lane) >> drop) != kones) return false;
-  *hq = (window_top(cur.h, prev.h, lane) >> drop) == kones;
-  const uint64_t x0 = window_top(cur.l0, prev.l0, lane), x1 = window_top(cur.l1, prev.l1, lane);
-  // forward mer: base i (i = 0 newest) is window bit 63-i -> bit-reverse
-  const uint32_t m0 = (uint32_t)(__builtin_bitreverse64(x0) & kones);
-  const uint32_t m1 = (uint32_t)(__builtin_bitreverse64(x1) & kones);
+                                             uint64_t* pkey, uint32_t* hq) {
+  const uint32_t kones = (uint32_t)((1ull << k) - 1);
+  const int drop = 32 - k;
+  if ((window_top32(cur.v, prev.v, lane) >> drop) != kones) return false;
+  *hq = (window_top32(cur.h, prev.h, lane) >> drop) == kones;
+  const uint32_t x0 = window_top32(cur.l0, prev.l0, lane), x1 = window_top32(cur.l1, prev.l1, lane);
+  // forward mer: base i (i = 0 newest) is window bit 31-i -> bit-reverse
+  const uint32_t m0 = __builtin_bitreverse32(x0) & kones, m1 = __builtin_bitreverse32(x1) & kones;
   // reverse complement: base i = 3 - (forward base k-1-i) -> complemented window, oldest base lowest
-  const uint32_t r0 = (uint32_t)((~x0) >> drop), r1 = (uint32_t)((~x1) >> drop);
-  const uint64_t m = spread32(m0) | (spread32(m1) << 1);
-  const uint64_t rm = spread32(r0) | (spread32(r1) << 1);
-  *key = m < rm ? m : rm;  // create_database.cc:86
+  const uint32_t r0 = (~x0) >> drop, r1 = (~x1) >> drop;
+  // m < rm as 2-bit packed integers (create_database.cc:86): decided at the most significant base
+  // where they differ, comparing (high bit, low bit) there
+  const uint32_t d = (m0 ^ r0) | (m1 ^ r1);
+  bool fwd = true;  // palindrome: either
+  if (d) {
+    const int t = 31 - __clz((int)d);
+    const uint32_t mv = (((m1 >> t) & 1u) << 1) | ((m0 >> t) & 1u);
+    const uint32_t rv = (((r1 >> t) & 1u) << 1) | ((r0 >> t) & 1u);
+    fwd = mv < rv;
+  }
+  const uint32_t c0 = fwd ? m0 : r0, c1 = fwd ? m1 : r1;
+  *pkey = (uint64_t)c0 | ((uint64_t)c1 << k);
   return true;
 }
 

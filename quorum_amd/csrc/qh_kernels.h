@@ -49,11 +49,6 @@ void qh_launch_insert_items(const uint64_t* items, uint64_t n, const unsigned lo
 void qh_launch_rehash(const uint64_t* old_table, const qh_geom& og, uint64_t* new_table,
                       const qh_geom& ng, qh_meta* meta, hipStream_t s);
 
-// record table -> items bucketed by owner shard (multi-GPU exchange front end)
-void qh_launch_extract_partitioned(const uint8_t* buf, const uint4* recs, qh_meta* meta,
-                                   const qh_geom& g, uint64_t* out, uint64_t cap_per_shard,
-                                   unsigned long long* counts, hipStream_t s);
-
 // --- radix-partitioned build (qh_partition.hip) -------------------------------------
 // destination of one partition level
 struct qh_part_dst {
@@ -94,3 +89,4 @@ void qh_launch_dump(const uint64_t* table, const qh_geom& g, uint64_t* mers, uin
 // --- roofline microbenchmarks -------------------------------------------------------
 void qh_launch_random_access(uint64_t* table, int lsize, uint64_t n, int mode, uint64_t seed,
                              unsigned long long* sink, hipStream_t s);
+void qh_launch_lds_rate(int mode, int iters, int blocks, unsigned long long* sink, hipStream_t s);

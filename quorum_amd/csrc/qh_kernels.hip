@@ -226,7 +226,7 @@ __global__ __launch_bounds__(QH_BLOCK) void k_insert_items(const uint64_t* __res
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t it = items[i];
     const uint32_t q = (uint32_t)(it & 1);
-    const uint64_t h = hashed ? ((it >> 1) & g.kmask) : qh_mix((it >> 1) & g.kmask, g.k);
+    const uint64_t h = hashed ? ((it >> 1) & g.kmask) : qh_hash_key((it >> 1) & g.kmask, g.k);
     const qh_pos p = qh_locate_hash(g, h);
     if (p.shard != (uint32_t)g.shard_id) { ++n_foreign; continue; }
     ++n_inst; n_hq += q;
@@ -285,62 +285,6 @@ void qh_launch_rehash(const uint64_t* old_table, const qh_geom& og, uint64_t* ne
                       qh_meta* meta, hipStream_t s) {
   hipLaunchKernelGGL(k_rehash, dim3(grid_for(qh_table_slots(og), QH_BLOCK, 8192)), dim3(QH_BLOCK), 0, s, old_table,
                      og, new_table, ng, meta);
-}
-
-// Multi-GPU front end: the chunk's items bucketed by owner shard. One atomic per
-// (wave, shard, 64-base block) reserves the output range.
-__global__ __launch_bounds__(QH_BLOCK) void k_extract_partitioned(const uint8_t* __restrict__ buf,
-                                                                  const uint4* __restrict__ recs,
-                                                                  qh_meta* __restrict__ meta, const qh_geom g,
-                                                                  uint64_t* __restrict__ out,
-                                                                  uint64_t cap_per_shard,
-                                                                  unsigned long long* __restrict__ counts) {
-  if (meta->format_err) return;
-  const uint32_t nrec = meta->nrec;
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-  const uint32_t nshards = 1u << g.shard_bits;
-  uint32_t n_inst = 0, n_hq = 0;
-  for (uint32_t r = __builtin_amdgcn_readfirstlane(wave0); r < nrec; r += nwaves) {
-    const uint4 rc = recs[r];
-    const uint32_t s0 = rc.x, len = rc.y, q0 = rc.z;
-    qh_planes prev = {0, 0, 0, 0};
-    for (uint32_t c0 = 0; c0 < len; c0 += 64) {
-      const qh_planes cur = qh_load_planes(buf, s0, q0, len, c0, lane, g.min_qual);
-      uint64_t key = 0;
-      uint32_t q = 0;
-      const bool emit = qh_lane_kmer(cur, prev, lane, g.k, &key, &q);
-      const uint32_t shard = emit ? qh_locate(g, key).shard : 0xFFFFFFFFu;
-      n_inst += emit; n_hq += emit ? q : 0;
-      for (uint32_t s = 0; s < nshards; ++s) {
-        const uint64_t mask = __ballot(shard == s);
-        if (!mask) continue;
-        unsigned long long base = 0;
-        if (lane == (int)(__ffsll((unsigned long long)mask) - 1))
-          base = atomicAdd(&counts[s], (unsigned long long)__popcll(mask));
-        base = __shfl(base, __ffsll((unsigned long long)mask) - 1, 64);
-        if (shard == s) {
-          const unsigned long long at = base + lanes_below(mask);
-          if (at < cap_per_shard) out[(uint64_t)s * cap_per_shard + at] = (key << 1) | q;
-          else meta->ovf_lost = 1;
-        }
-      }
-      prev = cur;
-    }
-  }
-  n_inst = wave_sum_u32(n_inst); n_hq = wave_sum_u32(n_hq);
-  if (lane == 0 && n_inst) {
-    atomicAdd(reinterpret_cast<unsigned long long*>(&meta->instances), (unsigned long long)n_inst);
-    atomicAdd(reinterpret_cast<unsigned long long*>(&meta->hq_instances), (unsigned long long)n_hq);
-  }
-}
-
-void qh_launch_extract_partitioned(const uint8_t* buf, const uint4* recs, qh_meta* meta, const qh_geom& g,
-                                   uint64_t* out, uint64_t cap_per_shard, unsigned long long* counts,
-                                   hipStream_t s) {
-  hipLaunchKernelGGL(k_extract_partitioned, dim3(2048), dim3(QH_BLOCK), 0, s, buf, recs, meta, g, out,
-                     cap_per_shard, counts);
 }
 
 // ---------------------------------------------------------------------- read side
@@ -542,4 +486,40 @@ __global__ __launch_bounds__(QH_BLOCK) void k_random_access(uint64_t* __restrict
 void qh_launch_random_access(uint64_t* table, int lsize, uint64_t n, int mode, uint64_t seed,
                              unsigned long long* sink, hipStream_t s) {
   hipLaunchKernelGGL(k_random_access, dim3(8192), dim3(QH_BLOCK), 0, s, table, lsize, n, mode, seed, sink);
+}
+
+// LDS operation-rate microbenchmark (design input for k_window_build): every lane performs `iters`
+// operations at pseudo-random slots of a 128 KiB LDS array.
+// mode 0 ds_read_b64, 1 ds_write_b64, 2 ds_cmpst_rtn_b64, 3 ds_cmpst_rtn_b32, 4 ds_add_rtn_u32,
+//      5 ds_add_u32 (no return), 6 ds_add_rtn_u64, 7 read_b64 + write_b64 + read_b64 (write-verify)
+__global__ __launch_bounds__(1024) void k_lds_rate(int mode, int iters, unsigned long long* __restrict__ sink) {
+  __shared__ unsigned long long a[16384];
+  unsigned int* a32 = reinterpret_cast<unsigned int*>(a);
+  for (int i = threadIdx.x; i < 16384; i += 1024) a[i] = i;
+  __syncthreads();
+  unsigned int x = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+  unsigned long long acc = 0;
+  for (int i = 0; i < iters; ++i) {
+    x = x * 1664525u + 1013904223u;
+    const unsigned int idx = (x >> 10) & 16383u;
+    switch (mode) {
+      case 0: acc += __hip_atomic_load(&a[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break;
+      case 1: __hip_atomic_store(&a[idx], (unsigned long long)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break;
+      case 2: acc += atomicCAS(&a[idx], (unsigned long long)idx, (unsigned long long)x); break;
+      case 3: acc += atomicCAS(&a32[idx * 2], idx, x); break;
+      case 4: acc += atomicAdd(&a32[idx * 2], 1u); break;
+      case 5: atomicAdd(&a32[idx * 2], 1u); break;
+      case 6: acc += atomicAdd(&a[idx], 1ull); break;
+      default: {
+        const unsigned long long o = __hip_atomic_load(&a[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&a[idx], o + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        acc += __hip_atomic_load(&a[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+  if (acc == 0x123456789abcdefull) *sink = acc;
+}
+
+void qh_launch_lds_rate(int mode, int iters, int blocks, unsigned long long* sink, hipStream_t s) {
+  hipLaunchKernelGGL(k_lds_rate, dim3(blocks), dim3(1024), 0, s, mode, iters, sink);
 }

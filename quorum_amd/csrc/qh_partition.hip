@@ -264,7 +264,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
         if (j < src_n) {
           const uint64_t raw = src[j];
           const uint32_t q = (uint32_t)(raw & 1);
-          const uint64_t h = p.in_hashed ? ((raw >> 1) & g.kmask) : qh_mix((raw >> 1) & g.kmask, g.k);
+          const uint64_t h = p.in_hashed ? ((raw >> 1) & g.kmask) : qh_hash_key((raw >> 1) & g.kmask, g.k);
           if (p.check_owner && ((uint32_t)h & smask) != (uint32_t)g.shard_id) {
             ++n_foreign;
           } else {
@@ -450,8 +450,9 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
   const int gsize = g.lsize + g.shard_bits;
   const uint32_t wmask = (1u << QH_WINDOW_BITS) - 1;
   uint32_t n_new = 0;
+  const uint64_t vkeep = ~g.vmask, one_probe = 1ull << g.vbits;
   for (uint64_t base = 0; base < n; base += (uint64_t)QW_UNROLL * QP_THREADS) {
-    uint64_t v[QW_UNROLL], old[QW_UNROLL];
+    uint64_t v[QW_UNROLL];
 #pragma unroll
     for (int u = 0; u < QW_UNROLL; ++u) v[u] = nxt[u];
     // next batch's loads are issued before this batch's LDS work
@@ -460,26 +461,63 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
       const uint64_t j = base + (uint64_t)(QW_UNROLL + u) * QP_THREADS + tid;
       nxt[u] = j < n ? src[j] : QP_NONE;
     }
+    if (ablate & 1) {  // timing-only build (QH_ABLATE)
 #pragma unroll
-    for (int u = 0; u < QW_UNROLL; ++u) {
-      const uint32_t loc = (uint32_t)((v[u] >> 1) >> g.shard_bits) & wmask;
-      old[u] = v[u] != QP_NONE ? __hip_atomic_load(&win[loc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+      for (int u = 0; u < QW_UNROLL; ++u) n_new += (uint32_t)v[u];
+      continue;
     }
+    // QW_UNROLL independent insert chains per lane, one LDS compare-and-swap per chain and
+    // round. A chain's CAS doubles as its read: "claim" rounds expect 0 and offer a fresh
+    // entry, "update" rounds expect the value the previous round returned.
+    // want = (remainder | probe+1) << vbits: the slot word of our key at this probe with a zero value
+    uint64_t want[QW_UNROLL], cmp[QW_UNROLL], nw[QW_UNROLL];
+    uint32_t pos[QW_UNROLL], left[QW_UNROLL], fresh[QW_UNROLL];
+    bool live[QW_UNROLL];
 #pragma unroll
     for (int u = 0; u < QW_UNROLL; ++u) {
-      if (v[u] == QP_NONE) continue;
       const uint64_t h = v[u] >> 1;
-      const uint32_t q = (uint32_t)(v[u] & 1);
-      const uint32_t loc = (uint32_t)(h >> g.shard_bits) & wmask;
-      const uint64_t tag0 = (gsize >= 64 ? 0 : (h >> gsize)) << g.pbits;
-      uint32_t is_new = 0;
-      if (ablate & 1) { n_new += (uint32_t)(old[u] + tag0); continue; }  // timing-only build (QH_ABLATE)
-      if (!qh_insert_lds(g, win, loc, tag0, q, old[u], &is_new)) {
-        const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(&meta->spill_count), 1ull);
-        if (at < spill_cap) spill[at] = v[u];
-        else meta->ovf_lost = 1;
+      live[u] = v[u] != QP_NONE;
+      pos[u] = (uint32_t)(h >> g.shard_bits) & wmask;
+      want[u] = (((gsize >= 64 ? 0 : (h >> gsize)) << g.pbits) | 1) << g.vbits;
+      left[u] = (uint32_t)g.max_reprobe;     // probes left after this one
+      fresh[u] = (v[u] & 1) ? 3u : 2u;       // value of a new entry (mer_database.hpp:105-110 from 0)
+      cmp[u] = 0;
+      nw[u] = want[u] | fresh[u];
+    }
+    while (live[0] | live[1] | live[2] | live[3]) {
+      uint64_t prev[QW_UNROLL];
+#pragma unroll
+      for (int u = 0; u < QW_UNROLL; ++u)
+        if (live[u])
+          prev[u] = atomicCAS(reinterpret_cast<unsigned long long*>(&win[pos[u]]), (unsigned long long)cmp[u],
+                              (unsigned long long)nw[u]);
+#pragma unroll
+      for (int u = 0; u < QW_UNROLL; ++u) {
+        if (!live[u]) continue;
+        if (prev[u] == cmp[u]) {                       // the swap happened
+          n_new += cmp[u] == 0;
+          live[u] = false;
+        } else if ((prev[u] & vkeep) == want[u]) {     // our key lives here: update round
+          uint64_t nv;
+          if (!qh_update_val(prev[u] & g.vmask, fresh[u] & 1u, g.max_val, &nv)) {
+            live[u] = false;                           // saturated / LQ instance of an HQ mer
+          } else {
+            cmp[u] = prev[u];
+            nw[u] = want[u] | nv;
+          }
+        } else if (left[u] == 0) {                     // reprobe limit: leave it to the direct path
+          const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(&meta->spill_count), 1ull);
+          if (at < spill_cap) spill[at] = v[u];
+          else meta->ovf_lost = 1;
+          live[u] = false;
+        } else {                                       // another key: next probe, claim round again
+          --left[u];
+          pos[u] = (pos[u] + 1) & wmask;
+          want[u] += one_probe;
+          cmp[u] = 0;
+          nw[u] = want[u] | fresh[u];
+        }
       }
-      n_new += is_new;
     }
   }
   n_new = wave_sum_u32(n_new);

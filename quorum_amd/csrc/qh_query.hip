@@ -289,3 +289,25 @@ extern "C" int qh_bench_random_access(int device, int lsize, uint64_t n_updates,
   *ms = total / iters;
   return QH_OK;
 }
+
+// lane-operations per second of one kind of LDS operation (see k_lds_rate), chip-wide
+extern "C" int qh_bench_lds_rate(int device, int mode, int iters, double* lane_ops_per_s) {
+  if (!lane_ops_per_s || mode < 0 || mode > 7 || iters < 1) return qh_fail(QH_EBADARG, "bad argument");
+  QH_HIP(hipSetDevice(device));
+  unsigned long long* sink = nullptr;
+  QH_HIP(hipMalloc((void**)&sink, 8));
+  hipEvent_t e0, e1;
+  QH_HIP(hipEventCreate(&e0));
+  QH_HIP(hipEventCreate(&e1));
+  const int blocks = 1024;
+  qh_launch_lds_rate(mode, iters, blocks, sink, nullptr);
+  QH_HIP(hipEventRecord(e0, nullptr));
+  qh_launch_lds_rate(mode, iters, blocks, sink, nullptr);
+  QH_HIP(hipEventRecord(e1, nullptr));
+  QH_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  QH_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(sink);
+  *lane_ops_per_s = (double)blocks * 1024.0 * iters * (mode == 7 ? 3.0 : 1.0) / (ms * 1e-3);
+  return QH_OK;
+}

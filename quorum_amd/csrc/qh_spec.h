@@ -11,7 +11,11 @@
 //   63 ............................................................. 0
 //   [ remainder : rbits ][ probe+1 : pbits ][ value = count<<1|hq : vbits ]
 //
-// h   = qh_mix(canonical k-mer)            bijection on 2k-bit integers
+// pk  = qh_pkey(canonical k-mer)           the key's two bit planes side by side:
+//                                          low bits of the k codes | high bits << k
+//                                          (a fixed bit permutation of the 2-bit packing;
+//                                          it is what the wave-parallel extractor produces)
+// h   = qh_mix(pk)                         bijection on 2k-bit integers
 // owner shard = h & (2^shard_bits - 1)     (0 when the table is not sharded; it does
 //                                           not depend on lsize, so a shard can double)
 // local home  = (h >> shard_bits) & (2^lsize - 1)
@@ -94,6 +98,38 @@ QH_HD uint64_t qh_revcomp(uint64_t m, int k) {
   return x >> (64 - 2 * k);
 }
 
+// even bits of x gathered into the low 32 bits
+QH_HD uint32_t qh_compress_even(uint64_t x) {
+  x &= 0x5555555555555555ULL;
+  x = (x | (x >> 1)) & 0x3333333333333333ULL;
+  x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0FULL;
+  x = (x | (x >> 4)) & 0x00FF00FF00FF00FFULL;
+  x = (x | (x >> 8)) & 0x0000FFFF0000FFFFULL;
+  x = (x | (x >> 16)) & 0x00000000FFFFFFFFULL;
+  return (uint32_t)x;
+}
+
+// 32 bits spread to the even bit positions of a 64-bit word
+QH_HD uint64_t qh_spread_even(uint32_t v) {
+  uint64_t x = v;
+  x = (x | (x << 16)) & 0x0000FFFF0000FFFFULL;
+  x = (x | (x << 8)) & 0x00FF00FF00FF00FFULL;
+  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0FULL;
+  x = (x | (x << 2)) & 0x3333333333333333ULL;
+  x = (x | (x << 1)) & 0x5555555555555555ULL;
+  return x;
+}
+
+// 2-bit packed k-mer <-> plane key (low code bits | high code bits << k)
+QH_HD uint64_t qh_pkey(uint64_t key, int k) {
+  return (uint64_t)qh_compress_even(key) | ((uint64_t)qh_compress_even(key >> 1) << k);
+}
+
+QH_HD uint64_t qh_key_from_pkey(uint64_t pk, int k) {
+  const uint32_t km = (uint32_t)((1ULL << k) - 1);
+  return qh_spread_even((uint32_t)pk & km) | (qh_spread_even((uint32_t)(pk >> k) & km) << 1);
+}
+
 QH_HD uint64_t qh_canonical(uint64_t m, int k) {
   const uint64_t r = qh_revcomp(m, k);
   return m < r ? m : r;
@@ -129,7 +165,10 @@ QH_HD qh_pos qh_locate_hash(const qh_geom& g, uint64_t h) {
   return p;
 }
 
-QH_HD qh_pos qh_locate(const qh_geom& g, uint64_t key) { return qh_locate_hash(g, qh_mix(key, g.k)); }
+// hash of a 2-bit packed (canonical) k-mer
+QH_HD uint64_t qh_hash_key(uint64_t key, int k) { return qh_mix(qh_pkey(key, k), k); }
+
+QH_HD qh_pos qh_locate(const qh_geom& g, uint64_t key) { return qh_locate_hash(g, qh_hash_key(key, g.k)); }
 
 QH_HD uint64_t qh_probe_idx(const qh_geom& g, uint64_t home, uint32_t i) {
   const uint64_t wmask = qh_low_mask(g.wbits);
@@ -152,7 +191,7 @@ QH_HD uint64_t qh_slot_hash(const qh_geom& g, uint64_t slot, uint64_t idx) {
 
 // key stored in the occupied slot word `slot` found at index `idx`
 QH_HD uint64_t qh_slot_key(const qh_geom& g, uint64_t slot, uint64_t idx) {
-  return qh_unmix(qh_slot_hash(g, slot, idx), g.k);
+  return qh_key_from_pkey(qh_unmix(qh_slot_hash(g, slot, idx), g.k), g.k);
 }
 
 // Quorum's update rule (src/mer_database.hpp:104-110) on a value field.

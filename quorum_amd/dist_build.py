@@ -17,9 +17,36 @@ MIX_C1 = np.uint64(0xff51afd7ed558ccd)
 MIX_C2 = np.uint64(0xc4ceb9fe1a85ec53)
 
 
+def _compress_even(x):
+    x = x & np.uint64(0x5555555555555555)
+    for sh, m in ((1, 0x3333333333333333), (2, 0x0F0F0F0F0F0F0F0F), (4, 0x00FF00FF00FF00FF),
+                  (8, 0x0000FFFF0000FFFF), (16, 0x00000000FFFFFFFF)):
+        x = (x | (x >> np.uint64(sh))) & np.uint64(m)
+    return x
+
+
+def _spread_even(x):
+    x = x & np.uint64(0xFFFFFFFF)
+    for sh, m in ((16, 0x0000FFFF0000FFFF), (8, 0x00FF00FF00FF00FF), (4, 0x0F0F0F0F0F0F0F0F),
+                  (2, 0x3333333333333333), (1, 0x5555555555555555)):
+        x = (x | (x << np.uint64(sh))) & np.uint64(m)
+    return x
+
+
+def pkey_np(mers, k):
+    """qh_pkey: 2-bit packed mers -> plane keys (low code bits | high code bits << k)"""
+    mers = np.asarray(mers, dtype=np.uint64)
+    return _compress_even(mers) | (_compress_even(mers >> np.uint64(1)) << np.uint64(k))
+
+
+def key_from_pkey_np(pk, k):
+    pk = np.asarray(pk, dtype=np.uint64)
+    km = np.uint64((1 << k) - 1)
+    return _spread_even(pk & km) | (_spread_even((pk >> np.uint64(k)) & km) << np.uint64(1))
+
+
 def mix_np(x, k):
-    """qh_mix (quorum_amd/csrc/qh_spec.h) on a uint64 array: the position hash whose low
-    shard_bits select the owner shard"""
+    """qh_mix (quorum_amd/csrc/qh_spec.h) on a uint64 array of plane keys"""
     x = np.asarray(x, dtype=np.uint64).copy()
     n = 2 * k
     s = np.uint64((n + 1) >> 1)
@@ -33,8 +60,32 @@ def mix_np(x, k):
     return x
 
 
+def unmix_np(x, k):
+    x = np.asarray(x, dtype=np.uint64).copy()
+    n = 2 * k
+    s = np.uint64((n + 1) >> 1)
+    m = np.uint64((1 << n) - 1)
+    with np.errstate(over="ignore"):
+        x ^= x >> s
+        x = (x * np.uint64(0x9cb4b2f8129337db)) & m
+        x ^= x >> s
+        x = (x * np.uint64(0x4f74430c22a54005)) & m
+        x ^= x >> s
+    return x
+
+
+def hash_np(mers, k):
+    """qh_hash_key: the position hash of 2-bit packed canonical mers"""
+    return mix_np(pkey_np(mers, k), k)
+
+
+def unhash_np(h, k):
+    return key_from_pkey_np(unmix_np(h, k), k)
+
+
 def owner_np(mers, k, shard_bits):
-    return (mix_np(mers, k) & np.uint64((1 << shard_bits) - 1)).astype(np.int64)
+    """owner shard of 2-bit packed canonical mers = low shard_bits of their hash"""
+    return (hash_np(mers, k) & np.uint64((1 << shard_bits) - 1)).astype(np.int64)
 
 
 def exchange_items(send, send_counts, group=None):
@@ -91,7 +142,7 @@ class ShardedBuilder:
         send = torch.cat([self._buckets[s, :counts[s]] for s in range(self.world)])
         recv, _ = exchange_items(send, counts, self.group)
         if recv.numel():
-            self.h.add_mers_device(recv.data_ptr(), recv.numel())
+            self.h.add_hashed_device(recv.data_ptr(), recv.numel())
             self.h.sync()  # recv must stay alive until the insert kernel has consumed it
 
     def reset(self):

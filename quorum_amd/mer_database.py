@@ -105,6 +105,10 @@ class HashWithQuality:
     def add_mers_device(self, dev_ptr, n):
         check(lib.qh_build_add_mers_device(self._h, C.c_void_p(dev_ptr), n))
 
+    def add_hashed_device(self, dev_ptr, n):
+        """items in the library's hashed exchange form (qh_build_extract_partitioned_device)"""
+        check(lib.qh_build_add_hashed_device(self._h, C.c_void_p(dev_ptr), n))
+
     def set_stream(self, stream_handle):
         check(lib.qh_build_set_stream(self._h, C.c_void_p(stream_handle)))
 

@@ -95,9 +95,15 @@ def test_sharded_exchange_gloo(world, tmp_path):
 def test_mix_np_is_the_library_hash():
     """dist_build.mix_np restates qh_mix; check bijectivity and the pinned constants"""
     sys.path.insert(0, ROOT)
-    from quorum_amd.dist_build import mix_np
+    from quorum_amd.dist_build import mix_np, unmix_np, pkey_np, key_from_pkey_np, hash_np, unhash_np
     for k in (4, 5, 8):
         x = np.arange(4 ** k, dtype=np.uint64)
         h = mix_np(x, k)
         assert np.unique(h).size == x.size and int(h.max()) < 4 ** k
+        assert (unmix_np(h, k) == x).all()
+        pk = pkey_np(x, k)
+        assert np.unique(pk).size == x.size and (key_from_pkey_np(pk, k) == x).all()
+        assert (unhash_np(hash_np(x, k), k) == x).all()
+    # ACGT = 00 01 10 11: low bits 0101 -> 0b0101, high bits 0011
+    assert int(pkey_np(np.array([0x1B], dtype=np.uint64), 4)[0]) == 0b0011_0101
     assert mix_np(np.array([0x123456789ABC], dtype=np.uint64), 24)[0] == mix_np(np.array([0x123456789ABC], dtype=np.uint64), 24)[0]

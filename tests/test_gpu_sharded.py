@@ -11,7 +11,7 @@ import torch
 import pyoracle as po
 import quorum_amd as qa
 from quorum_amd import _lib, synth
-from quorum_amd.dist_build import owner_np
+from quorum_amd.dist_build import owner_np, unhash_np
 from helpers import sorted_pairs
 
 pytestmark = pytest.mark.gpu
@@ -37,8 +37,10 @@ def test_sharded_build_single_process(shard_bits, tmp_path):
     assert sum(cnt) == ninst
     for s in range(n):
         items = buckets[s, :cnt[s]].cpu().numpy().view(np.uint64)
-        assert (owner_np(items >> np.uint64(1), k, shard_bits) == s).all()   # python restatement == device owner
-        hs[s].add_mers_device(buckets[s].data_ptr(), cnt[s])
+        hashes = items >> np.uint64(1)
+        assert ((hashes & np.uint64(n - 1)) == s).all()                      # owner = low shard_bits of the hash
+        assert (owner_np(unhash_np(hashes, k), k, shard_bits) == s).all()    # python restatement == device hash
+        hs[s].add_hashed_device(buckets[s].data_ptr(), cnt[s])
         hs[s].sync()
     om, ov = db.sorted_dump()
     dumps = [h.dump() for h in hs]
