@@ -385,35 +385,17 @@ void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsign
 
 // ----------------------------------------------------------------- window build
 
-// hash_with_quality::add on a window held in LDS (same slot format and probe rule as
-// qh_insert, local index instead of a global one). `old` is the caller's (possibly
-// stale) read of probe 0: every decision taken on it is re-validated by the CAS.
-__device__ __forceinline__ bool qh_insert_lds(const qh_geom& g, uint64_t* win, uint32_t loc, uint64_t tag0,
-                                              uint32_t q, uint64_t old, uint32_t* is_new) {
-  const uint32_t wmask = (1u << QH_WINDOW_BITS) - 1;
-  const uint64_t fresh = q ? 3u : 2u;
-  for (uint32_t i = 0; i <= (uint32_t)g.max_reprobe; ++i) {
-    unsigned long long* slot = reinterpret_cast<unsigned long long*>(win + ((loc + i) & wmask));
-    const uint64_t want = tag0 | (i + 1);
-    if (i) old = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    for (;;) {
-      if (old == 0) {
-        const uint64_t prev = atomicCAS(slot, 0ull, (unsigned long long)((want << g.vbits) | fresh));
-        if (prev == 0) { *is_new = 1; return true; }
-        old = prev;
-      }
-      if ((old >> g.vbits) != want) break;
-      uint64_t nv;
-      if (!qh_update_val(old & g.vmask, q, g.max_val, &nv)) return true;
-      const uint64_t prev = atomicCAS(slot, (unsigned long long)old, (unsigned long long)((old & ~g.vmask) | nv));
-      if (prev == old) return true;
-      old = prev;
-    }
-  }
-  return false;
-}
-
-#define QW_UNROLL 4
+// One workgroup per window. hash_with_quality::add (src/mer_database.hpp:94-113) on a window
+// held in LDS, same slot format and probe rule as qh_insert.
+//
+// Every lane runs one insert chain: one LDS compare-and-swap per round, the CAS doubling as the
+// read ("claim" rounds expect 0 and offer a fresh entry; "update" rounds expect the word the
+// previous round returned). Probe lengths differ wildly between lanes, so a lane whose chain
+// ends is handed the wave's next item at once: each wave owns a contiguous segment of the
+// bucket, streams it 64 items at a time through a private LDS ring (one coalesced global load
+// in flight ahead of use), and deals items to idle lanes by ballot rank. Nearly every CAS
+// wave-instruction therefore carries 64 live lanes.
+#define QW_RING 192  // items per wave ring (1.5 KiB)
 
 __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restrict__ table, const qh_geom g,
                                                              const uint64_t* __restrict__ items, uint64_t cap,
@@ -422,20 +404,21 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
                                                              uint64_t spill_cap, qh_meta* __restrict__ meta,
                                                              int ablate) {
   __shared__ uint64_t win[1u << QH_WINDOW_BITS];
+  __shared__ uint64_t ring[QP_WAVES][QW_RING];
   __shared__ uint32_t wnew[QP_WAVES];
   const uint32_t w = blockIdx.x;
   uint64_t n = counts[w];
   if (n > cap) n = cap;
   if (n == 0) return;  // nothing to add: the window stays as it is
-  const int tid = threadIdx.x;
-  const uint64_t* src = items + (uint64_t)w * cap;
-  // first batch of items in flight while the window is brought into LDS
-  uint64_t nxt[QW_UNROLL];
-#pragma unroll
-  for (int u = 0; u < QW_UNROLL; ++u) {
-    const uint64_t j = (uint64_t)u * QP_THREADS + tid;
-    nxt[u] = j < n ? src[j] : QP_NONE;
-  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // this wave's segment of the bucket
+  const uint32_t seg = (uint32_t)((n + QP_WAVES - 1) / QP_WAVES);
+  const uint32_t s0 = (uint32_t)(((uint64_t)wave * seg) < n ? (uint64_t)wave * seg : n);
+  const uint32_t seg_n = (uint32_t)((uint64_t)s0 + seg <= n ? seg : n - s0);
+  const uint64_t* src = items + (uint64_t)w * cap + s0;
+  // first 64 items in flight while the window is brought into LDS
+  uint64_t pend = (uint32_t)lane < seg_n ? src[lane] : QP_NONE;
+  bool pending = seg_n > 0;
   uint4* tw = reinterpret_cast<uint4*>(table + ((uint64_t)w << QH_WINDOW_BITS));
   uint4* lw = reinterpret_cast<uint4*>(win);
   const uint32_t nvec = (1u << QH_WINDOW_BITS) / 2;  // 16-byte pieces
@@ -447,81 +430,101 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
     for (uint32_t i = 0; i < nvec / QP_THREADS; ++i) lw[i * QP_THREADS + tid] = make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
+
   const int gsize = g.lsize + g.shard_bits;
   const uint32_t wmask = (1u << QH_WINDOW_BITS) - 1;
-  uint32_t n_new = 0;
   const uint64_t vkeep = ~g.vmask, one_probe = 1ull << g.vbits;
-  for (uint64_t base = 0; base < n; base += (uint64_t)QW_UNROLL * QP_THREADS) {
-    uint64_t v[QW_UNROLL];
-#pragma unroll
-    for (int u = 0; u < QW_UNROLL; ++u) v[u] = nxt[u];
-    // next batch's loads are issued before this batch's LDS work
-#pragma unroll
-    for (int u = 0; u < QW_UNROLL; ++u) {
-      const uint64_t j = base + (uint64_t)(QW_UNROLL + u) * QP_THREADS + tid;
-      nxt[u] = j < n ? src[j] : QP_NONE;
+  uint64_t* myring = ring[wave];
+  uint32_t head = 0, tail = 0;          // items dealt / items in the ring so far (wave-uniform)
+  uint32_t head_mod = 0, tail_mod = 0;  // the same modulo QW_RING
+  uint32_t n_new = 0;
+  // chain state
+  bool live = false;
+  uint64_t v = 0, want = 0, cmp = 0, nw = 0;
+  uint32_t pos = 0, left = 0, fresh = 0;
+
+  for (;;) {
+    uint32_t avail = tail - head;
+    // commit the load in flight once the ring runs low
+    if (pending && avail < 64) {
+      uint32_t at = tail_mod + lane;
+      if (at >= QW_RING) at -= QW_RING;
+      myring[at] = pend;
+      const uint32_t got = seg_n - tail < 64 ? seg_n - tail : 64;
+      tail += got;
+      tail_mod += got;
+      if (tail_mod >= QW_RING) tail_mod -= QW_RING;
+      pending = false;
+      avail = tail - head;
     }
-    if (ablate & 1) {  // timing-only build (QH_ABLATE)
-#pragma unroll
-      for (int u = 0; u < QW_UNROLL; ++u) n_new += (uint32_t)v[u];
+    // keep one 64-item load in flight ahead of use
+    if (!pending && tail < seg_n && avail <= QW_RING - 64) {
+      pend = tail + lane < seg_n ? src[tail + lane] : QP_NONE;
+      pending = true;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // deal items to idle lanes
+    const uint64_t need = __ballot(!live);
+    if (need && avail) {
+      const uint32_t cnt = (uint32_t)__popcll((unsigned long long)need);
+      const uint32_t give = cnt < avail ? cnt : avail;
+      const uint32_t rank = lanes_below(need);
+      if (!live && rank < give) {
+        uint32_t at = head_mod + rank;
+        if (at >= QW_RING) at -= QW_RING;
+        v = __hip_atomic_load(&myring[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint64_t h = v >> 1;
+        pos = (uint32_t)(h >> g.shard_bits) & wmask;
+        // want = (remainder | probe+1) << vbits: our key's slot word at this probe with a zero value
+        want = (((gsize >= 64 ? 0 : (h >> gsize)) << g.pbits) | 1) << g.vbits;
+        left = (uint32_t)g.max_reprobe;  // probes left after this one
+        fresh = (v & 1) ? 3u : 2u;       // value of a new entry (mer_database.hpp:105-110 from 0)
+        cmp = 0;
+        nw = want | fresh;
+        live = true;
+      }
+      head += give;
+      head_mod += give;
+      if (head_mod >= QW_RING) head_mod -= QW_RING;
+    } else if (need == ~0ull && !pending && head == seg_n) {
+      break;  // every lane idle, nothing left to deal
+    }
+    if (ablate & 1) {  // timing-only build (QH_ABLATE): no insertion
+      n_new += (uint32_t)v;
+      live = false;
       continue;
     }
-    // QW_UNROLL independent insert chains per lane, one LDS compare-and-swap per chain and
-    // round. A chain's CAS doubles as its read: "claim" rounds expect 0 and offer a fresh
-    // entry, "update" rounds expect the value the previous round returned.
-    // want = (remainder | probe+1) << vbits: the slot word of our key at this probe with a zero value
-    uint64_t want[QW_UNROLL], cmp[QW_UNROLL], nw[QW_UNROLL];
-    uint32_t pos[QW_UNROLL], left[QW_UNROLL], fresh[QW_UNROLL];
-    bool live[QW_UNROLL];
-#pragma unroll
-    for (int u = 0; u < QW_UNROLL; ++u) {
-      const uint64_t h = v[u] >> 1;
-      live[u] = v[u] != QP_NONE;
-      pos[u] = (uint32_t)(h >> g.shard_bits) & wmask;
-      want[u] = (((gsize >= 64 ? 0 : (h >> gsize)) << g.pbits) | 1) << g.vbits;
-      left[u] = (uint32_t)g.max_reprobe;     // probes left after this one
-      fresh[u] = (v[u] & 1) ? 3u : 2u;       // value of a new entry (mer_database.hpp:105-110 from 0)
-      cmp[u] = 0;
-      nw[u] = want[u] | fresh[u];
-    }
-    while (live[0] | live[1] | live[2] | live[3]) {
-      uint64_t prev[QW_UNROLL];
-#pragma unroll
-      for (int u = 0; u < QW_UNROLL; ++u)
-        if (live[u])
-          prev[u] = atomicCAS(reinterpret_cast<unsigned long long*>(&win[pos[u]]), (unsigned long long)cmp[u],
-                              (unsigned long long)nw[u]);
-#pragma unroll
-      for (int u = 0; u < QW_UNROLL; ++u) {
-        if (!live[u]) continue;
-        if (prev[u] == cmp[u]) {                       // the swap happened
-          n_new += cmp[u] == 0;
-          live[u] = false;
-        } else if ((prev[u] & vkeep) == want[u]) {     // our key lives here: update round
-          uint64_t nv;
-          if (!qh_update_val(prev[u] & g.vmask, fresh[u] & 1u, g.max_val, &nv)) {
-            live[u] = false;                           // saturated / LQ instance of an HQ mer
-          } else {
-            cmp[u] = prev[u];
-            nw[u] = want[u] | nv;
-          }
-        } else if (left[u] == 0) {                     // reprobe limit: leave it to the direct path
-          const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(&meta->spill_count), 1ull);
-          if (at < spill_cap) spill[at] = v[u];
-          else meta->ovf_lost = 1;
-          live[u] = false;
-        } else {                                       // another key: next probe, claim round again
-          --left[u];
-          pos[u] = (pos[u] + 1) & wmask;
-          want[u] += one_probe;
-          cmp[u] = 0;
-          nw[u] = want[u] | fresh[u];
+    // one round
+    if (live) {
+      const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&win[pos]), (unsigned long long)cmp,
+                                      (unsigned long long)nw);
+      if (prev == cmp) {                          // the swap happened
+        n_new += cmp == 0;
+        live = false;
+      } else if ((prev & vkeep) == want) {        // our key lives here: update round
+        uint64_t nv;
+        if (!qh_update_val(prev & g.vmask, fresh & 1u, g.max_val, &nv)) {
+          live = false;                           // saturated / LQ instance of an HQ mer
+        } else {
+          cmp = prev;
+          nw = want | nv;
         }
+      } else if (left == 0) {                     // reprobe limit: leave it to the direct path
+        const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(&meta->spill_count), 1ull);
+        if (at < spill_cap) spill[at] = v;
+        else meta->ovf_lost = 1;
+        live = false;
+      } else {                                    // another key: next probe, claim round again
+        --left;
+        pos = (pos + 1) & wmask;
+        want += one_probe;
+        cmp = 0;
+        nw = want | fresh;
       }
     }
   }
   n_new = wave_sum_u32(n_new);
-  if ((tid & 63) == 0) wnew[tid >> 6] = n_new;
+  if (lane == 0) wnew[wave] = n_new;
   __syncthreads();
   if (!(ablate & 2)) {
 #pragma unroll
