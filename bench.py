@@ -125,7 +125,9 @@ def main():
         avgs = [ms / n if n else 0.0 for ms, n in ktimes]
         dom = max(range(4), key=lambda i: avgs[i])
         kernel_avg_ms, klaunch = avgs[dom], ktimes[dom][1]
-        knames = ("k_build_direct" if world == 1 else "k_insert_items", "k_partition<level 1>", "k_partition<level 2>", "k_window_build")
+        # names as rocprofv3 prints them: k_partition<0> = FASTQ source (level 1), k_partition<1> = item source
+        knames = ("k_build_direct" if world == 1 else "k_insert_items", "k_partition<0>" if world == 1 else "k_partition<1> (level 1)",
+                  "k_partition<1>" if world == 1 else "k_partition<1> (level 2)", "k_window_build")
         per_launch = st["instances"]                # this rank's insertions per launch of the dominant kernel
         achieved = per_launch * ALG_BYTES_PER_KMER / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
         traffic = None
@@ -149,6 +151,7 @@ def main():
                        "slots_per_gpu": int(st["slots"]), "parallelism": "hash-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "whole_step_frac": per_launch * ALG_BYTES_PER_KMER / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                          "kernel": knames[dom],
                          "kernel_avg_ms": kernel_avg_ms, "kernel_launches": int(klaunch),
                          "all_kernels_avg_ms": {knames[i]: avgs[i] for i in range(4) if avgs[i] > 0},

@@ -138,7 +138,7 @@ extern "C" void qh_build_destroy(qh_build* h) {
   if (!h) return;
   hipError_t e = hipSetDevice(h->device); (void)e;
   if (h->stream) { e = hipStreamSynchronize(h->stream); (void)e; }
-  void* ptrs[] = {h->table, h->d_meta, h->d_chunk, h->d_recs, h->d_tiles, h->d_ovf[0], h->d_ovf[1], h->d_items, h->d_shard_counts, h->d_blkprefix, h->d_rbsums, h->d_blkrec,
+  void* ptrs[] = {h->table, h->d_meta, h->d_chunk, h->d_recs, h->d_tiles, h->d_ovf[0], h->d_ovf[1], h->d_items, h->d_shard_counts, h->d_blkprefix, h->d_rbsums, h->d_blkdesc,
                   h->d_bins[0], h->d_bins[1], h->d_bin_counts[0], h->d_bin_counts[1]};
   for (void* p : ptrs) if (p) { e = hipFree(p); (void)e; }
   if (h->h_meta) { e = hipHostFree(h->h_meta); (void)e; }
@@ -327,8 +327,11 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
   const qh_geom& g = h->g;
   const int wid_bits = g.lsize - QH_WINDOW_BITS;
   const uint32_t nw = 1u << wid_bits;
-  int b1 = wid_bits <= 12 ? wid_bits : (wid_bits + 1) / 2;
-  if (h->level1_bits >= 0 && h->level1_bits < wid_bits && wid_bits - h->level1_bits <= 12) b1 = h->level1_bits;
+  // measured on MI355X (profiles/): a 256-way last level after a coarse first level beats one
+  // 4096-way level (2.24 ms vs 2.45 ms for 152 M items); tables of up to 256 windows use one level
+  int b1 = wid_bits <= 8 ? wid_bits : wid_bits - 8;
+  if (b1 > 12) b1 = 12;
+  if (h->level1_bits >= 0 && h->level1_bits <= wid_bits && wid_bits - h->level1_bits <= 12) b1 = h->level1_bits;
   const int b2 = wid_bits - b1;
   const size_t capw = max_items / nw + max_items / nw / 5 + 512;
   const size_t cap1 = b2 ? max_items / ((size_t)1 << b1) + max_items / ((size_t)1 << b1) / 10 + 4096 : 0;
@@ -358,9 +361,9 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
   if (src.fastq) {
     if ((rc = ensure((void**)&h->d_rbsums, &h->rbsums_cap, (src.rec_cap / 1024 + 4) * 4, "record block sums"))) return rc;
     if ((rc = ensure((void**)&h->d_blkprefix, &h->blkprefix_cap, (src.rec_cap + 2) * 4, "record block prefix"))) return rc;
-    if ((rc = ensure((void**)&h->d_blkrec, &h->blkrec_cap, (src.max_blocks + 2) * 4, "block records"))) return rc;
-    qh_launch_rec_blocks(h->d_recs, (uint32_t)src.rec_cap, h->d_meta, h->d_rbsums, h->d_blkprefix, h->d_blkrec, h->stream);
-    qh_launch_partition_fastq(src.fastq, h->d_recs, h->d_blkprefix, h->d_blkrec, h->d_meta, g, l1_dst, check_owner, h->stream);
+    if ((rc = ensure((void**)&h->d_blkdesc, &h->blkdesc_cap, (src.max_blocks + 2) * 16, "block descriptors"))) return rc;
+    qh_launch_rec_blocks(h->d_recs, (uint32_t)src.rec_cap, h->d_meta, h->d_rbsums, h->d_blkprefix, h->d_blkdesc, h->stream);
+    qh_launch_partition_fastq(src.fastq, h->d_recs, h->d_blkprefix, h->d_blkdesc, h->d_meta, g, l1_dst, check_owner, h->stream);
   } else {
     qh_launch_partition_items(src.items, src.n_items, nullptr, 1, src.n_items, src.hashed, h->d_meta, g, l1_dst,
                               check_owner, 1, h->stream);
@@ -655,12 +658,12 @@ extern "C" int qh_build_extract_partitioned_device(qh_build* h, const void* dev_
   const size_t max_blocks = len / 64 + rec_cap;
   if ((rc = ensure((void**)&h->d_rbsums, &h->rbsums_cap, (rec_cap / 1024 + 4) * 4, "record block sums"))) return rc;
   if ((rc = ensure((void**)&h->d_blkprefix, &h->blkprefix_cap, (rec_cap + 2) * 4, "record block prefix"))) return rc;
-  if ((rc = ensure((void**)&h->d_blkrec, &h->blkrec_cap, (max_blocks + 2) * 4, "block records"))) return rc;
-  qh_launch_rec_blocks(h->d_recs, (uint32_t)rec_cap, h->d_meta, h->d_rbsums, h->d_blkprefix, h->d_blkrec, h->stream);
+  if ((rc = ensure((void**)&h->d_blkdesc, &h->blkdesc_cap, (max_blocks + 2) * 16, "block descriptors"))) return rc;
+  qh_launch_rec_blocks(h->d_recs, (uint32_t)rec_cap, h->d_meta, h->d_rbsums, h->d_blkprefix, h->d_blkdesc, h->stream);
   // bucket = owner shard = low shard_bits of the hash; a bucket that overflows is an error here
   qh_part_dst dst = {dev_out, cap_per_shard, (unsigned long long*)dev_counts, 0, h->g.shard_bits, 0, nullptr, 0};
   timing_begin(h, 1);
-  qh_launch_partition_fastq((const uint8_t*)dev_buf, h->d_recs, h->d_blkprefix, h->d_blkrec, h->d_meta, h->g, dst, 0, h->stream);
+  qh_launch_partition_fastq((const uint8_t*)dev_buf, h->d_recs, h->d_blkprefix, h->d_blkdesc, h->d_meta, h->g, dst, 0, h->stream);
   timing_end(h, 1);
   QH_HIP(hipGetLastError());
   // format / capacity verdict of this call

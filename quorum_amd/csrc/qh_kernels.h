@@ -62,11 +62,11 @@ struct qh_part_dst {
 };
 // record table -> exclusive prefix of 64-base blocks (blk_prefix[nrec] = total);
 // tile_sums needs ceil(rec_cap/1024)+1 words
-// and the record of every block (blk_rec, one word per block)
+// and the descriptor of every block (blk_desc, 16 bytes per block)
 void qh_launch_rec_blocks(const uint4* recs, uint32_t rec_cap, const qh_meta* meta, uint32_t* tile_sums,
-                          uint32_t* blk_prefix, uint32_t* blk_rec, hipStream_t s);
+                          uint32_t* blk_prefix, uint4* blk_desc, hipStream_t s);
 void qh_launch_partition_fastq(const uint8_t* buf, const uint4* recs, const uint32_t* blk_prefix,
-                               const uint32_t* blk_rec, qh_meta* meta,
+                               const uint4* blk_desc, qh_meta* meta,
                                const qh_geom& g, const qh_part_dst& d, int check_owner, hipStream_t s);
 void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsigned long long* in_counts,
                                uint32_t n_in_buckets, uint64_t in_n, int in_hashed, qh_meta* meta, const qh_geom& g,

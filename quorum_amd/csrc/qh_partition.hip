@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void k_rec_blocks_apply(const uint4* __restric
                                                           const uint32_t* __restrict__ tile_prefix,
                                                           const uint32_t* __restrict__ total,
                                                           uint32_t* __restrict__ blk_prefix,
-                                                          uint32_t* __restrict__ blk_rec) {
+                                                          uint4* __restrict__ blk_desc) {
   __shared__ uint32_t wtot[4];
   const uint32_t nrec = meta->format_err ? 0 : meta->nrec;
   const uint32_t base = blockIdx.x * RB_TILE;
@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void k_rec_blocks_apply(const uint4* __restric
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (uint32_t j = 0; j < RB_TILE; j += 256) {
     const uint32_t r = base + j + threadIdx.x;
-    const uint32_t c = r < nrec ? (recs[r].y + 63) >> 6 : 0;
+    const uint4 rc = r < nrec ? recs[r] : make_uint4(0, 0, 0, 0);
+    const uint32_t c = (rc.y + 63) >> 6;
     uint32_t inc = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -104,7 +105,12 @@ __global__ __launch_bounds__(256) void k_rec_blocks_apply(const uint4* __restric
     if (r < nrec) {
       const uint32_t pb = run + wbase + inc - c;
       blk_prefix[r] = pb;
-      for (uint32_t b = 0; b < c; ++b) blk_rec[pb + b] = r;  // record of every 64-base block
+      // descriptor of every 64-base block: {sequence offset, quality offset, bases in the block,
+      // index of the block inside its read}
+      for (uint32_t b = 0; b < c; ++b) {
+        const uint32_t left = rc.y - b * 64;
+        blk_desc[pb + b] = make_uint4(rc.x + b * 64, rc.z + b * 64, left < 64 ? left : 64, b);
+      }
     }
     run += tot;
     __syncthreads();
@@ -113,12 +119,12 @@ __global__ __launch_bounds__(256) void k_rec_blocks_apply(const uint4* __restric
 }
 
 void qh_launch_rec_blocks(const uint4* recs, uint32_t rec_cap, const qh_meta* meta, uint32_t* tile_sums,
-                          uint32_t* blk_prefix, uint32_t* blk_rec, hipStream_t s) {
+                          uint32_t* blk_prefix, uint4* blk_desc, hipStream_t s) {
   const uint32_t ntiles = (rec_cap + RB_TILE - 1) / RB_TILE;
   // tile_sums[ntiles] receives the total
   hipLaunchKernelGGL(k_rec_blocks_sum, dim3(ntiles), dim3(256), 0, s, recs, meta, tile_sums);
   hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, tile_sums, ntiles, tile_sums + ntiles);
-  hipLaunchKernelGGL(k_rec_blocks_apply, dim3(ntiles), dim3(256), 0, s, recs, meta, tile_sums, tile_sums + ntiles, blk_prefix, blk_rec);
+  hipLaunchKernelGGL(k_rec_blocks_apply, dim3(ntiles), dim3(256), 0, s, recs, meta, tile_sums, tile_sums + ntiles, blk_prefix, blk_desc);
 }
 
 // ------------------------------------------------------------- LDS-staged multi-split
@@ -140,7 +146,7 @@ struct qp_params {
   const uint8_t* buf;
   const uint4* recs;
   const uint32_t* blk_prefix;
-  const uint32_t* blk_rec;
+  const uint4* blk_desc;
   // SRC_ITEMS: input bucket b = blockIdx.y holds in[b * in_cap ...], in_counts[b] items (or in_n when in_counts == 0)
   const uint64_t* in;
   uint64_t in_cap;
@@ -189,6 +195,47 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
   }
   const uint32_t in_bucket = SRC == QP_SRC_ITEMS ? blockIdx.y : 0;
 
+  // Software pipeline over this workgroup's tiles: the inputs of tile t+1 are requested while
+  // tile t is sorted and written out (one workgroup per CU: nothing else would hide the latency).
+  // FASTQ: lane s < 13 holds the descriptor of block g0-1+s (slot 0 is the block before the wave's
+  // first one: a k-mer's window reaches k-1 bases back); the 26 byte loads of a tile are issued
+  // together, unconditionally (lanes past a block's end re-read its first byte and are masked when
+  // the planes are formed).
+  uint4 dcur = make_uint4(0, 0, 0, 0), dnext = make_uint4(0, 0, 0, 0);
+  uint8_t bb[QP_BLOCKS_PER_WAVE + 1];
+  int8_t qq[QP_BLOCKS_PER_WAVE + 1];
+  uint64_t raw[QP_BLOCKS_PER_WAVE];
+  auto load_desc = [&](uint64_t tile) -> uint4 {
+    const uint64_t gb = tile * QP_TILE_BLOCKS + (uint64_t)wave * QP_BLOCKS_PER_WAVE + lane;  // block + 1
+    if (lane <= QP_BLOCKS_PER_WAVE && gb >= 1 && gb - 1 < nblk) return p.blk_desc[gb - 1];
+    return make_uint4(0, 0, 0, 0);
+  };
+  auto issue_bytes = [&](const uint4& d) {
+#pragma unroll
+    for (int sl = 0; sl <= QP_BLOCKS_PER_WAVE; ++sl) {
+      const uint32_t so = __builtin_amdgcn_readlane(d.x, sl), qo = __builtin_amdgcn_readlane(d.y, sl);
+      const uint32_t nv = __builtin_amdgcn_readlane(d.z, sl);
+      const uint32_t l = (uint32_t)lane < nv ? (uint32_t)lane : 0u;
+      bb[sl] = p.buf[(size_t)so + l];
+      qq[sl] = (int8_t)p.buf[(size_t)qo + l];
+    }
+  };
+  auto issue_items = [&](uint64_t tile) {
+    const uint64_t j0 = tile * QP_TILE_ITEMS + (uint64_t)wave * (QP_BLOCKS_PER_WAVE * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < QP_BLOCKS_PER_WAVE; ++i) {
+      const uint64_t j = j0 + (uint64_t)i * 64;
+      raw[i] = j < src_n ? src[j] : QP_NONE;
+    }
+  };
+  if (SRC == QP_SRC_FASTQ) {
+    dcur = load_desc(blockIdx.x);
+    issue_bytes(dcur);
+    dnext = load_desc((uint64_t)blockIdx.x + gridDim.x);
+  } else {
+    issue_items(blockIdx.x);
+  }
+
   for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     for (uint32_t b = tid; b < nbins; b += QP_THREADS) cursor[b] = 0;
     __syncthreads();
@@ -199,47 +246,20 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
     for (int i = 0; i < QP_BLOCKS_PER_WAVE; ++i) it[i] = QP_NONE;
 
     if (SRC == QP_SRC_FASTQ) {
-      // The wave owns blocks g0 .. g0+11. Lane s < 13 resolves block g0-1+s (slot 0 is the block
-      // before the first one: the window of a k-mer reaches k-1 bases back) to its record, then
-      // the bytes of all 13 blocks are requested before any of them is used.
-      const uint32_t g0 = (uint32_t)tile * QP_TILE_BLOCKS + wave * QP_BLOCKS_PER_WAVE;
-      uint32_t d_so = 0, d_qo = 0, d_n = 0, d_r = 0xFFFFFFFFu;
-      {
-        const uint32_t gb = g0 + lane - 1;
-        if (lane <= QP_BLOCKS_PER_WAVE && (lane > 0 || g0 > 0) && gb < nblk) {
-          const uint32_t r = p.blk_rec[gb];
-          const uint4 rc = p.recs[r];
-          const uint32_t off = (gb - p.blk_prefix[r]) * 64;
-          d_so = rc.x + off; d_qo = rc.z + off; d_r = r;
-          d_n = rc.y - off < 64 ? rc.y - off : 64;
-        }
-      }
-      // unconditional loads (lanes past the block's end re-read its first byte and are masked when
-      // the planes are formed): no branch around a load, so all 26 are in flight together
-      uint8_t bb[QP_BLOCKS_PER_WAVE + 1];
-      int8_t qq[QP_BLOCKS_PER_WAVE + 1];
-#pragma unroll
-      for (int sl = 0; sl <= QP_BLOCKS_PER_WAVE; ++sl) {
-        const uint32_t so = __builtin_amdgcn_readlane(d_so, sl), qo = __builtin_amdgcn_readlane(d_qo, sl);
-        const uint32_t nv = __builtin_amdgcn_readlane(d_n, sl);
-        const uint32_t l = (uint32_t)lane < nv ? (uint32_t)lane : 0u;
-        bb[sl] = p.buf[(size_t)so + l];
-        qq[sl] = (int8_t)p.buf[(size_t)qo + l];
-      }
       qh_planes prev = {0, 0, 0, 0};
-      uint32_t prev_r = 0xFFFFFFFFu;
 #pragma unroll
       for (int sl = 0; sl <= QP_BLOCKS_PER_WAVE; ++sl) {
-        const uint32_t r = __builtin_amdgcn_readlane(d_r, sl);
+        const uint32_t nv = __builtin_amdgcn_readlane(dcur.z, sl);
+        const uint32_t jblk = __builtin_amdgcn_readlane(dcur.w, sl);
         const int code = qh_code(bb[sl]);
-        const bool valid = code >= 0 && (uint32_t)lane < (uint32_t)__builtin_amdgcn_readlane(d_n, sl);
+        const bool valid = code >= 0 && (uint32_t)lane < nv;
         qh_planes cur;
         cur.v = __ballot(valid);
         cur.h = __ballot(valid && (int)qq[sl] >= (int)(int8_t)g.min_qual);
         cur.l0 = __ballot(valid && (code & 1));
         cur.l1 = __ballot(valid && (code & 2));
-        if (sl > 0 && r != 0xFFFFFFFFu) {
-          if (r != prev_r) prev = qh_planes{0, 0, 0, 0};  // first block of its record
+        if (sl > 0 && nv) {
+          if (jblk == 0) prev = qh_planes{0, 0, 0, 0};  // first block of its read
           uint64_t key;
           uint32_t q;
           if (qh_lane_kmer(cur, prev, lane, g.k, &key, &q)) {
@@ -254,17 +274,17 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
           }
         }
         prev = cur;
-        prev_r = r;
       }
+      // next tile: its bytes now (descriptors arrived an iteration ago), the descriptors after it
+      dcur = dnext;
+      issue_bytes(dcur);
+      dnext = load_desc(tile + 2ull * gridDim.x);
     } else {
-      const uint64_t j0 = tile * QP_TILE_ITEMS + (uint64_t)wave * (QP_BLOCKS_PER_WAVE * 64) + lane;
 #pragma unroll
       for (int i = 0; i < QP_BLOCKS_PER_WAVE; ++i) {
-        const uint64_t j = j0 + (uint64_t)i * 64;
-        if (j < src_n) {
-          const uint64_t raw = src[j];
-          const uint32_t q = (uint32_t)(raw & 1);
-          const uint64_t h = p.in_hashed ? ((raw >> 1) & g.kmask) : qh_hash_key((raw >> 1) & g.kmask, g.k);
+        if (raw[i] != QP_NONE) {
+          const uint32_t q = (uint32_t)(raw[i] & 1);
+          const uint64_t h = p.in_hashed ? ((raw[i] >> 1) & g.kmask) : qh_hash_key((raw[i] >> 1) & g.kmask, g.k);
           if (p.check_owner && ((uint32_t)h & smask) != (uint32_t)g.shard_id) {
             ++n_foreign;
           } else {
@@ -274,10 +294,12 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
           }
         }
       }
+      issue_items(tile + gridDim.x);
     }
     __syncthreads();
 
     // ---- exclusive scan of the histogram (4 bins per thread), bucket space reservation
+    uint32_t resv[4] = {0, 0, 0, 0};
     {
       uint32_t c[4], s = 0;
 #pragma unroll
@@ -309,9 +331,10 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
         if (b < nbins) {
           offs[b] = run;
           cursor[b] = run;
-          gbase[b] = c[e] ? (uint32_t)atomicAdd(&p.out_counts[((uint64_t)in_bucket << p.out_bin_shift) | b],
-                                                (unsigned long long)c[e])
-                          : 0u;
+          // reserve the bucket range now, look at the answer only after the placement pass
+          resv[e] = c[e] ? (uint32_t)atomicAdd(&p.out_counts[((uint64_t)in_bucket << p.out_bin_shift) | b],
+                                               (unsigned long long)c[e])
+                         : 0u;
           run += c[e];
         }
       }
@@ -326,6 +349,9 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
         sorted[atomicAdd(&cursor[b], 1u)] = it[i];
       }
     }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if ((uint32_t)tid * 4 + e < nbins) gbase[tid * 4 + e] = resv[e];
     __syncthreads();
 
     // ---- stream the tile out: consecutive lanes of one bucket write consecutive words
@@ -360,11 +386,11 @@ static void fill_common(qp_params& p, const qh_part_dst& d, qh_meta* meta, int c
 }
 
 void qh_launch_partition_fastq(const uint8_t* buf, const uint4* recs, const uint32_t* blk_prefix,
-                               const uint32_t* blk_rec, qh_meta* meta,
+                               const uint4* blk_desc, qh_meta* meta,
                                const qh_geom& g, const qh_part_dst& d, int check_owner, hipStream_t s) {
   qp_params p = {};
   fill_common(p, d, meta, check_owner, 1);
-  p.buf = buf; p.recs = recs; p.blk_prefix = blk_prefix; p.blk_rec = blk_rec;
+  p.buf = buf; p.recs = recs; p.blk_prefix = blk_prefix; p.blk_desc = blk_desc;
   hipLaunchKernelGGL(k_partition<QP_SRC_FASTQ>, dim3(256), dim3(QP_THREADS), 0, s, p, g);
 }
 
