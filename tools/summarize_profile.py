@@ -1,0 +1,41 @@
+"""Copies the judged summaries of a tools/profile_bench.sh run from gpurun_out/prof_<tag>/
+into profiles/<name>/ : kernel_stats.csv, domain_stats.csv, pmc_summary.json, and writes
+profiles/pmc_traffic.json (HBM bytes per launch of the dominant kernel, for bench.py)."""
+import collections, csv, glob, json, os, shutil, sys
+
+tag, name = sys.argv[1], sys.argv[2]
+src = "gpurun_out/prof_%s" % tag
+dst = "profiles/%s" % name
+os.makedirs(dst, exist_ok=True)
+for kind in ("kernel_stats", "domain_stats"):
+    f = glob.glob("%s/trace/*/*%s.csv" % (src, kind))
+    if f:
+        shutil.copy(f[0], "%s/%s.csv" % (dst, kind))
+out = {}
+for sub in ("pmc_fetch", "pmc_write"):
+    f = glob.glob("%s/%s/*/*counter_collection.csv" % (src, sub))
+    if not f:
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f[0])):
+        agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        for c, x in v.items():
+            out.setdefault(k, {})[c] = {"launches": len(x), "avg": sum(x) / len(x)}
+json.dump(out, open("%s/pmc_summary.json" % dst, "w"), indent=1, sort_keys=True)
+# per-launch HBM traffic of each kernel, corrected as MI355X_MICROARCH.md prescribes:
+# FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half of a wide coalesced read.
+traffic = {}
+for k, v in out.items():
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        traffic[k] = {"fetch_bytes_raw": v["FETCH_SIZE"]["avg"] * 1024, "fetch_bytes_x2": v["FETCH_SIZE"]["avg"] * 2048,
+                      "write_bytes": v["WRITE_SIZE"]["avg"] * 1024}
+stats = {}
+f = "%s/kernel_stats.csv" % dst
+if os.path.exists(f):
+    for r in csv.DictReader(open(f)):
+        stats[r["Name"].split("(")[0]] = float(r["AverageNs"])
+json.dump({"per_kernel": traffic, "avg_ns": stats}, open("%s/traffic.json" % dst, "w"), indent=1, sort_keys=True)
+for k in sorted(stats, key=lambda k: -stats[k])[:8]:
+    t = traffic.get(k, {})
+    print("%-45s %9.1f us  fetch(x2) %8.1f MB  write %8.1f MB" % (k[:45], stats[k] / 1e3, t.get("fetch_bytes_x2", 0) / 1e6, t.get("write_bytes", 0) / 1e6))
