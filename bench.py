@@ -71,10 +71,17 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
+    # QH_DIST_BACKEND=gloo + QH_SHARE_GPU=1: rehearsal of the N>1 path with all ranks on GPU 0
+    backend = os.environ.get("QH_DIST_BACKEND", "nccl")
+    if os.environ.get("QH_SHARE_GPU"):
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from quorum_amd import synth
     from quorum_amd.dist_build import ShardedBuilder
@@ -112,8 +119,9 @@ def main():
     ktimes = [b.h.kernel_time(i) for i in range(4)]
     st = b.h.stats()
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    inst = torch.tensor([float(st["instances"])], dtype=torch.float64, device=dev)
+    rdev = dev if backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([dt], dtype=torch.float64, device=rdev)
+    inst = torch.tensor([float(st["instances"])], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(inst, op=dist.ReduceOp.SUM)

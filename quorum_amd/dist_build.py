@@ -96,6 +96,10 @@ def exchange_items(send, send_counts, group=None):
     Works on CUDA tensors (RCCL) and CPU tensors (gloo)."""
     world = dist.get_world_size(group)
     dev = send.device
+    if dev.type == "cuda" and dist.get_backend(group) == "gloo":
+        # rehearsal mode (several ranks sharing one GPU, no RCCL): stage through the host
+        recv, recv_counts = exchange_items(send.cpu(), send_counts, group)
+        return recv.to(dev), recv_counts
     sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
     rc = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_to_all_single(rc, sc, group=group)

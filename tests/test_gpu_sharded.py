@@ -76,3 +76,24 @@ def test_sharded_build_single_process(shard_bits, tmp_path):
     q.close()
     for h in hs:
         h.close()
+
+
+def test_two_rank_bench_rehearsal():
+    """bench.py's N>1 path end to end (extract+bucket by owner, all-to-all, insert) with two ranks
+    sharing the one GPU and gloo standing in for RCCL; also checks the sharded result."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, QH_DIST_BACKEND="gloo", QH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29571", os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "200000"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    # 2 ranks x 200k reads x (100-24+1) windows, minus the windows that contain an N
+    assert 0.97 * 2 * 200000 * 77 < d["config"]["insertions_per_step"] <= 2 * 200000 * 77
