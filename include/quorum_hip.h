@@ -102,6 +102,11 @@ int qh_build_add_fastq(qh_build* h, const char* buf, size_t len);
 int qh_build_add_fastq_host_parsed(qh_build* h, const char* buf, size_t len,
                                    int final_chunk, size_t* consumed);
 
+/* Every canonical k-mer of a FASTA buffer ('>' header line, sequence lines up to the next
+ * line starting with '>'), each with the quality bit set: the input side of the contaminant
+ * set (src/error_correct_reads.cc:86-90 inserts the keys `jellyfish count -C` found). */
+int qh_build_add_fasta(qh_build* h, const char* buf, size_t len);
+
 /* Pre-indexed records over a device-resident buffer (record table in host memory). */
 int qh_build_add_records_device(qh_build* h, const void* dev_buf, size_t len,
                                 const qh_record* recs, size_t nrec);
@@ -214,6 +219,36 @@ int qh_query_best_alternatives_batch(qh_query* q, const uint64_t* fmers, const u
 /* compute_poisson_cutoff__'s table reduction (src/error_correct_reads.cc:650-659):
  * distinct = #{v : (v&1) && v>=2}, total = sum of their counts. */
 int qh_query_stats(qh_query* q, uint64_t* distinct, uint64_t* total);
+
+/* poisson_term(lambda, i) (src/error_correct_reads.cc:53-61): e^-lambda lambda^i / i!,
+ * Stirling's form from i = 11. */
+double qh_poisson_term(double lambda, unsigned i);
+
+/* compute_poisson_cutoff(mer_database.vals(), collision_prob, poisson_threshold)
+ * (src/error_correct_reads.cc:650-674; called at :712-715 with apriori_error_rate/3 and
+ * poisson_threshold/apriori_error_rate): table reduction on the GPU, then the first
+ * x in [2,1000) whose Poisson term falls under the threshold, plus one; 0 if none. */
+int qh_query_poisson_cutoff(qh_query* q, double collision_prob, double poisson_threshold,
+                            unsigned* cutoff);
+
+/* The contaminant set of src/error_correct_reads.cc:83-99,692-708, built directly from a
+ * FASTA file at mer length k (upstream: `jellyfish count -C` dump read back key by key,
+ * Makefile.am:54-55): every canonical k-mer of every record. Close with qh_query_close. */
+int qh_contaminant_open_fasta(qh_query** out, const char* fasta_path, int k, int device);
+
+/* contaminant_database::is_contaminant (src/error_correct_reads.cc:94) for a batch of
+ * canonical mers: flags[i] = 1 iff mers[i] is a key of `set`. */
+int qh_query_is_member_batch(qh_query* set, const uint64_t* mers, size_t n, uint8_t* flags);
+
+/* The database lookup and the contaminant test the corrector makes on the same canonical
+ * mer (src/error_correct_reads.cc:348,390,620) in one pass: out[i] as qh_query_batch (may be
+ * NULL), flags[i] as qh_query_is_member_batch. Both handles must have the same k
+ * (:703-705) and device. */
+int qh_query_batch_contaminant(qh_query* q, qh_query* contaminant, const uint64_t* mers, size_t n,
+                               uint64_t* out, uint8_t* flags);
+int qh_query_batch_contaminant_device(qh_query* q, qh_query* contaminant, const uint64_t* dev_mers,
+                                      size_t n, uint64_t* dev_out, uint8_t* dev_flags,
+                                      void* hip_stream);
 
 /* histo_mer_database (src/histo_mer_database.cc:13-21): histo[min(count,1000)][hq] */
 int qh_query_histo(qh_query* q, uint64_t* histo /* [1001][2] */);

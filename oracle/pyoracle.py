@@ -61,6 +61,14 @@ _o.qo_db_dump.restype = C.c_uint64
 _o.qo_db_dump.argtypes = [C.c_void_p, _u64p, _u64p, C.c_uint64]
 _o.qo_db_stats.argtypes = [C.c_void_p, _u64p, _u64p]
 _o.qo_db_histo.argtypes = [C.c_void_p, _u64p]
+_o.qo_poisson_term.restype = C.c_double
+_o.qo_poisson_term.argtypes = [C.c_double, C.c_uint]
+_o.qo_poisson_cutoff_from.restype = C.c_uint
+_o.qo_poisson_cutoff_from.argtypes = [C.c_uint64, C.c_uint64, C.c_double, C.c_double]
+_o.qo_db_poisson_cutoff.restype = C.c_uint
+_o.qo_db_poisson_cutoff.argtypes = [C.c_void_p, C.c_double, C.c_double]
+_o.qo_db_add_fasta.restype = C.c_int64
+_o.qo_db_add_fasta.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
 
 PARSE_ERRORS = {-1: "Truncated fastq file", -2: "Invalid fastq file: wrong number of quals",
                 -3: "Invalid fastq file: header missing", -4: "Unsupported format", -5: "out of capacity",
@@ -73,6 +81,16 @@ def revcomp(m, k):
 
 def canonical(m, k):
     return _o.qo_canonical(m, k)
+
+
+def poisson_term(lam, i):
+    """error_correct_reads.cc:53-61"""
+    return _o.qo_poisson_term(lam, i)
+
+
+def poisson_cutoff_from(distinct, total, collision_prob, poisson_threshold):
+    """error_correct_reads.cc:660-667 from the (distinct, total) reduction"""
+    return _o.qo_poisson_cutoff_from(distinct, total, collision_prob, poisson_threshold)
 
 
 def extract_read(seq, qual, k, thresh):
@@ -138,6 +156,17 @@ class OracleDB:
         if r < 0:
             raise ValueError(PARSE_ERRORS.get(r, str(r)))
         return r
+
+    def add_fasta(self, data):
+        """contaminant set: every canonical k-mer of a FASTA file, stored with quality 1"""
+        data = bytes(data)
+        r = _o.qo_db_add_fasta(self._db, data, len(data))
+        if r < 0:
+            raise ValueError(PARSE_ERRORS.get(r, str(r)))
+        return r
+
+    def poisson_cutoff(self, collision_prob, poisson_threshold):
+        return _o.qo_db_poisson_cutoff(self._db, collision_prob, poisson_threshold)
 
     def size(self):
         return _o.qo_db_size(self._db)

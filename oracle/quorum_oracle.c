@@ -36,6 +36,7 @@
  * Jellyfish headers and a yaggo-generated header that this image lacks.
  */
 #define _GNU_SOURCE
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -572,4 +573,68 @@ void qo_db_histo(const qo_db* db, uint64_t histo[1001][2]) {
     uint64_t c = v >> 1; if (c > 1000) c = 1000;
     ++histo[c][v & 1];
   }
+}
+
+/* ---------------------------------------------------------- Poisson cutoff */
+
+/* poisson_term (error_correct_reads.cc:53-61): e^-lambda lambda^i / i!, Stirling for i >= 11 */
+double qo_poisson_term(double lambda, unsigned i) {
+  static const double facts[11] = {1, 1, 2, 6, 24, 120, 720, 5040, 40320, 362880, 3628800};
+  static const double tau = 6.283185307179583;
+  if (i < 11) return exp(-lambda) * pow(lambda, i) / facts[i];
+  return exp(-lambda + i) * pow(lambda / i, i) / sqrt(tau * i);
+}
+
+/* compute_poisson_cutoff__ (error_correct_reads.cc:650-668) from the (distinct, total) reduction */
+unsigned qo_poisson_cutoff_from(uint64_t distinct, uint64_t total, double collision_prob, double poisson_threshold) {
+  const double coverage = (double)total / (double)distinct;
+  const double lambda = coverage * collision_prob;
+  for (unsigned x = 2; x < 1000; ++x)
+    if (qo_poisson_term(lambda, x) < poisson_threshold) return x + 1;
+  return 0;
+}
+
+unsigned qo_db_poisson_cutoff(const qo_db* db, double collision_prob, double poisson_threshold) {
+  uint64_t d, t;
+  qo_db_stats(db, &d, &t);
+  return qo_poisson_cutoff_from(d, t, collision_prob, poisson_threshold);
+}
+
+/* ------------------------------------------------- contaminant set (FASTA) */
+
+/* The set `jellyfish count -C -m k` makes of a FASTA file (Makefile.am:54-55) and
+ * contaminant_database loads key by key (error_correct_reads.cc:86-90): every canonical
+ * k-mer of every record, a non-ACGT character restarting the window.  FASTA as Jellyfish's
+ * whole_sequence_parser::read_fasta reads it: '>' header line, then sequence lines up to the
+ * next line that starts with '>'.  Members are stored with quality 1, so membership
+ * (mer_array::has_key, :94) is "lookup != 0".  Returns the number of instances, -4 when the
+ * first character is not '>', -10 when the table is full. */
+int64_t qo_db_add_fasta(qo_db* db, const char* buf, size_t len) {
+  if (len == 0) return 0;
+  if (buf[0] != '>') return -4;
+  char* seq = (char*)malloc(len + 1);
+  char* qual = (char*)malloc(len + 1);
+  uint64_t* mers = (uint64_t*)malloc((len + 1) * sizeof(uint64_t));
+  uint8_t* hq = (uint8_t*)malloc(len + 1);
+  memset(qual, 127, len + 1);
+  size_t p = 0;
+  int64_t total = 0;
+  uint64_t m = 0, rm = 0;
+  while (p < len && total >= 0) {
+    p = line_end(buf, len, p);            /* header line */
+    if (p < len) ++p;
+    size_t n = 0;
+    while (p < len && buf[p] != '>') {    /* sequence lines */
+      size_t e = line_end(buf, len, p);
+      memcpy(seq + n, buf + p, e - p);
+      n += e - p;
+      p = e < len ? e + 1 : e;
+    }
+    size_t cnt = qo_extract_read(seq, qual, n, db->k, 0, &m, &rm, mers, hq);
+    for (size_t j = 0; j < cnt; ++j)
+      if (qo_db_add(db, mers[j], 1)) { total = -10; break; }
+    if (total >= 0) total += (int64_t)cnt;
+  }
+  free(seq); free(qual); free(mers); free(hq);
+  return total;
 }

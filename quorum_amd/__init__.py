@@ -8,4 +8,5 @@ multi-GPU driver.  There is no CPU fallback: importing ``quorum_amd._lib`` raise
 the library has not been built.
 """
 from ._lib import lib, QhError, last_error  # noqa: F401
-from .mer_database import HashWithQuality, DatabaseQuery, mer_from_str, mer_to_str, revcomp, canonical  # noqa: F401
+from .mer_database import (HashWithQuality, DatabaseQuery, mer_from_str, mer_to_str, revcomp, canonical,  # noqa: F401
+                           poisson_term, contaminant_database)

@@ -50,6 +50,7 @@ SIGNATURES = [
     ("qh_build_add_fastq_device", C.c_int, [_p, _p, C.c_size_t]),
     ("qh_build_add_fastq", C.c_int, [_p, C.c_char_p, C.c_size_t]),
     ("qh_build_add_fastq_host_parsed", C.c_int, [_p, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_size_t)]),
+    ("qh_build_add_fasta", C.c_int, [_p, C.c_char_p, C.c_size_t]),
     ("qh_build_add_records_device", C.c_int, [_p, _p, C.c_size_t, C.POINTER(QhRecord), C.c_size_t]),
     ("qh_build_add_mers", C.c_int, [_p, _u64p, _u8p, C.c_size_t]),
     ("qh_build_add_mers_device", C.c_int, [_p, _p, C.c_size_t]),
@@ -75,6 +76,12 @@ SIGNATURES = [
     ("qh_query_best_alternatives_batch", C.c_int, [_p, _u64p, _u8p, C.c_size_t, _u64p, _i32p, _i32p, _i32p]),
     ("qh_query_stats", C.c_int, [_p, _u64p, _u64p]),
     ("qh_query_histo", C.c_int, [_p, _u64p]),
+    ("qh_poisson_term", C.c_double, [C.c_double, C.c_uint]),
+    ("qh_query_poisson_cutoff", C.c_int, [_p, C.c_double, C.c_double, C.POINTER(C.c_uint)]),
+    ("qh_contaminant_open_fasta", C.c_int, [C.POINTER(_p), C.c_char_p, C.c_int, C.c_int]),
+    ("qh_query_is_member_batch", C.c_int, [_p, _u64p, C.c_size_t, _u8p]),
+    ("qh_query_batch_contaminant", C.c_int, [_p, _p, _u64p, C.c_size_t, _u64p, _u8p]),
+    ("qh_query_batch_contaminant_device", C.c_int, [_p, _p, _p, C.c_size_t, _p, _p, _p]),
     ("qh_query_dump", C.c_int, [_p, _u64p, _u64p, C.c_uint64, _u64p]),
     ("qh_build_enable_timing", C.c_int, [_p, C.c_int]),
     ("qh_build_kernel_time", C.c_int, [_p, C.c_int, C.POINTER(C.c_double), _u64p]),

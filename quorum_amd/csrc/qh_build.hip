@@ -587,6 +587,79 @@ extern "C" int qh_build_add_fastq_host_parsed(qh_build* h, const char* buf, size
   return submit_records(h, h->d_chunk, recs.data(), recs.size(), total);
 }
 
+// Contaminant set input: every canonical k-mer of a FASTA buffer, all with the
+// quality bit set, through the same record path as FASTQ. FASTA as Jellyfish's
+// whole_sequence_parser::read_fasta reads it: '>' header line, then sequence lines up to the
+// next line that starts with '>'. Replaces `jellyfish count -C` (Makefile.am:54-55) + the
+// binary_reader loop of contaminant_database (error_correct_reads.cc:86-90).
+extern "C" int qh_build_add_fasta(qh_build* h, const char* buf, size_t len) {
+  if (!h) return qh_fail(QH_EBADARG, "null handle");
+  if (len == 0) return QH_OK;
+  if (!buf) return qh_fail(QH_EBADARG, "null buffer");
+  if (len > kMaxChunk / 2) return qh_fail(QH_EBADARG, "buffer larger than %zu bytes", kMaxChunk / 2);
+  if (buf[0] != '>') return qh_fail(QH_EFORMAT, "Unsupported format: the FASTA buffer does not start with '>'");
+  std::string seqs;
+  std::vector<qh_record> recs;
+  size_t p = 0, maxlen = 0, total = 0;
+  auto eol = [&](size_t from) -> size_t {
+    const void* e = from < len ? memchr(buf + from, '\n', len - from) : nullptr;
+    return e ? (size_t)((const char*)e - buf) : len;
+  };
+  while (p < len) {
+    p = eol(p);  // header line
+    if (p < len) ++p;
+    const size_t start = seqs.size();
+    while (p < len && buf[p] != '>') {
+      const size_t e = eol(p);
+      seqs.append(buf + p, e - p);
+      p = e < len ? e + 1 : e;
+    }
+    const size_t n = seqs.size() - start;
+    if (n > 0xFFFFFFFFull) return qh_fail(QH_EFORMAT, "sequence longer than 4 Gbases");
+    if (n) {
+      qh_record r;
+      r.seq_off = (uint32_t)start; r.len = (uint32_t)n; r.qual_off = 0; r.reserved = 0;
+      recs.push_back(r);
+      if (n > maxlen) maxlen = n;
+      total += n;
+    }
+  }
+  if (recs.empty()) return QH_OK;
+  // one shared run of maximal qualities serves every record
+  const std::string quals(maxlen, (char)127);
+  int rc = qh_build_sync(h);
+  if (rc) return rc;
+  QH_HIP(hipSetDevice(h->device));
+  size_t qoff = 0;
+  if ((rc = stage_chunk(h, seqs.data(), seqs.size(), quals.data(), quals.size(), &qoff))) return rc;
+  for (size_t i = 0; i < recs.size(); ++i) recs[i].qual_off = (uint32_t)qoff;
+  QH_HIP(hipStreamSynchronize(h->stream));
+  return submit_records(h, h->d_chunk, recs.data(), recs.size(), total);
+}
+
+// The contaminant database as error_correct_reads.cc:692-708 opens it, built from FASTA at the
+// run's k instead of read from a Jellyfish dump: a value-less set (bits = 1) whose membership
+// test is "lookup != 0" (contaminant_database::is_contaminant, :94).
+extern "C" int qh_contaminant_open_fasta(qh_query** out, const char* path, int k, int device) {
+  if (!out || !path) return qh_fail(QH_EBADARG, "null argument");
+  *out = nullptr;
+  FILE* f = fopen(path, "rb");
+  if (!f) return qh_fail(QH_EIO, "Failed to open contaminant file '%s'", path);
+  std::string data;
+  char tmp[1 << 16];
+  size_t got;
+  while ((got = fread(tmp, 1, sizeof tmp, f)) > 0) data.append(tmp, got);
+  fclose(f);
+  qh_build* b = nullptr;
+  int rc = qh_build_create(&b, k, 1, data.size() + 1024, 0, 126, device, 0, 0);
+  if (rc) return rc;
+  if ((rc = qh_build_add_fasta(b, data.data(), data.size())) || (rc = qh_build_sync(b))) { qh_build_destroy(b); return rc; }
+  rc = qh_query_from_table(b->device, b->table, b->g, out);
+  if (rc == QH_OK) { (*out)->owns_table = true; b->table = nullptr; }  // the set outlives its builder
+  qh_build_destroy(b);
+  return rc;
+}
+
 static int add_items_device(qh_build* h, const uint64_t* dev_items, size_t n, int hashed);
 
 extern "C" int qh_build_add_mers_device(qh_build* h, const uint64_t* dev_items, size_t n) {

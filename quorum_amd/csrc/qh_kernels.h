@@ -78,6 +78,9 @@ void qh_launch_window_build(uint64_t* table, const qh_geom& g, const uint64_t* i
 // --- read side ------------------------------------------------------------------------
 void qh_launch_lookup(const uint64_t* table, const qh_geom& g, const uint64_t* mers, uint64_t n,
                       uint64_t* out, int get_val, hipStream_t s);
+// out may be null (membership only); the two tables share k
+void qh_launch_lookup_contaminant(const uint64_t* table, const qh_geom& g, const uint64_t* ctable, const qh_geom& cg,
+                                  const uint64_t* mers, uint64_t n, uint64_t* out, uint8_t* flags, hipStream_t s);
 void qh_launch_best_alternatives(const uint64_t* table, const qh_geom& g, const uint64_t* fmers,
                                  const uint8_t* backward, uint64_t n, uint64_t* counts,
                                  int32_t* ucode, int32_t* level, int32_t* nkept, hipStream_t s);

@@ -320,6 +320,29 @@ void qh_launch_lookup(const uint64_t* table, const qh_geom& g, const uint64_t* m
   hipLaunchKernelGGL(k_lookup, dim3(grid_for(n, QH_BLOCK, 8192)), dim3(QH_BLOCK), 0, s, table, g, mers, n, out, get_val);
 }
 
+// database lookup and contaminant membership of the same canonical mer in one pass
+// (error_correct_reads.cc:348,390,620: is_contaminant(mer.canonical()) next to the
+// database_query lookup). flags[i] = 1 iff the mer is in the contaminant set.
+__global__ __launch_bounds__(QH_BLOCK) void k_lookup_contaminant(const uint64_t* __restrict__ table, const qh_geom g,
+                                                                 const uint64_t* __restrict__ ctable, const qh_geom cg,
+                                                                 const uint64_t* __restrict__ mers, uint64_t n,
+                                                                 uint64_t* __restrict__ out,
+                                                                 uint8_t* __restrict__ flags) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t m = mers[i];
+    const bool ok = !(m & ~g.kmask);
+    if (out) out[i] = ok ? qh_lookup(g, table, m) : 0;
+    flags[i] = ok && qh_lookup(cg, ctable, m) != 0;
+  }
+}
+
+void qh_launch_lookup_contaminant(const uint64_t* table, const qh_geom& g, const uint64_t* ctable, const qh_geom& cg,
+                                  const uint64_t* mers, uint64_t n, uint64_t* out, uint8_t* flags, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_lookup_contaminant, dim3(grid_for(n, QH_BLOCK, 8192)), dim3(QH_BLOCK), 0, s, table, g, ctable, cg,
+                     mers, n, out, flags);
+}
+
 // get_best_alternatives (mer_database.hpp:302-329): 4 lanes per mer, one per
 // alternative base; lane 0 of each quad folds the four (count, hq) pairs in
 // code order exactly like the upstream loop.

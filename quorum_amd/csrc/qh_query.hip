@@ -3,6 +3,7 @@
 // reductions its callers run (src/error_correct_reads.cc:650-659,
 // src/histo_mer_database.cc:13-21) and the roofline microbenchmark.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdio.h>
 #include <string.h>
 #include <unistd.h>
@@ -199,6 +200,70 @@ extern "C" int qh_query_stats(qh_query* q, uint64_t* distinct, uint64_t* total) 
   *distinct = q->h_meta->stat_distinct;
   *total = q->h_meta->stat_total;
   return QH_OK;
+}
+
+// poisson_term (error_correct_reads.cc:53-61)
+extern "C" double qh_poisson_term(double lambda, unsigned i) {
+  static const double facts[11] = {1, 1, 2, 6, 24, 120, 720, 5040, 40320, 362880, 3628800};
+  static const double tau = 6.283185307179583;
+  if (i < 11) return exp(-lambda) * pow(lambda, i) / facts[i];
+  return exp(-lambda + i) * pow(lambda / i, i) / sqrt(tau * i);
+}
+
+// compute_poisson_cutoff__ (error_correct_reads.cc:650-668): the full-table reduction runs on
+// the GPU (k_stats), the <= 998 Poisson terms on the host.
+extern "C" int qh_query_poisson_cutoff(qh_query* q, double collision_prob, double poisson_threshold, unsigned* cutoff) {
+  if (!q || !cutoff) return qh_fail(QH_EBADARG, "null argument");
+  uint64_t distinct = 0, total = 0;
+  int rc = qh_query_stats(q, &distinct, &total);
+  if (rc) return rc;
+  const double coverage = (double)total / (double)distinct;
+  const double lambda = coverage * collision_prob;
+  *cutoff = 0;
+  for (unsigned x = 2; x < 1000; ++x)
+    if (qh_poisson_term(lambda, x) < poisson_threshold) { *cutoff = x + 1; break; }
+  return QH_OK;
+}
+
+extern "C" int qh_query_batch_contaminant_device(qh_query* q, qh_query* contaminant, const uint64_t* dev_mers, size_t n,
+                                                 uint64_t* dev_out, uint8_t* dev_flags, void* hip_stream) {
+  if (!q || !contaminant) return qh_fail(QH_EBADARG, "null handle");
+  if (n == 0) return QH_OK;
+  if (!dev_mers || !dev_flags) return qh_fail(QH_EBADARG, "null buffer");
+  if (q->g.k != contaminant->g.k)  // error_correct_reads.cc:703-705
+    return qh_fail(QH_EBADARG, "Contaminant mer length (%d) different than correction mer length (%d)", contaminant->g.k, q->g.k);
+  if (q->device != contaminant->device) return qh_fail(QH_EBADARG, "database and contaminant set live on different devices");
+  QH_HIP(hipSetDevice(q->device));
+  qh_launch_lookup_contaminant(q->table, q->g, contaminant->table, contaminant->g, dev_mers, n, dev_out, dev_flags,
+                               hip_stream ? (hipStream_t)hip_stream : q->stream);
+  QH_HIP(hipGetLastError());
+  return QH_OK;
+}
+
+extern "C" int qh_query_batch_contaminant(qh_query* q, qh_query* contaminant, const uint64_t* mers, size_t n, uint64_t* out,
+                                          uint8_t* flags) {
+  if (!q || !contaminant) return qh_fail(QH_EBADARG, "null handle");
+  if (n == 0) return QH_OK;
+  if (!mers || !flags) return qh_fail(QH_EBADARG, "null buffer");
+  std::lock_guard<std::mutex> lock(q->mu);
+  QH_HIP(hipSetDevice(q->device));
+  int rc;
+  if ((rc = qh_ensure_device(&q->d_in, &q->in_cap, n * 8, "query keys"))) return rc;
+  if ((rc = qh_ensure_device(&q->d_in2, &q->in2_cap, n, "contaminant flags"))) return rc;
+  if ((rc = qh_ensure_device(&q->d_out, &q->out_cap, n * 8, "query results"))) return rc;
+  QH_HIP(hipMemcpyAsync(q->d_in, mers, n * 8, hipMemcpyHostToDevice, q->stream));
+  if ((rc = qh_query_batch_contaminant_device(q, contaminant, (const uint64_t*)q->d_in, n, out ? (uint64_t*)q->d_out : nullptr,
+                                              (uint8_t*)q->d_in2, q->stream)))
+    return rc;
+  if (out) QH_HIP(hipMemcpyAsync(out, q->d_out, n * 8, hipMemcpyDeviceToHost, q->stream));
+  QH_HIP(hipMemcpyAsync(flags, q->d_in2, n, hipMemcpyDeviceToHost, q->stream));
+  QH_HIP(hipStreamSynchronize(q->stream));
+  return QH_OK;
+}
+
+// contaminant_database::is_contaminant (error_correct_reads.cc:94) for a batch
+extern "C" int qh_query_is_member_batch(qh_query* set, const uint64_t* mers, size_t n, uint8_t* flags) {
+  return qh_query_batch_contaminant(set, set, mers, n, nullptr, flags);
 }
 
 extern "C" int qh_query_histo(qh_query* q, uint64_t* histo) {

@@ -102,6 +102,12 @@ class HashWithQuality:
         check(lib.qh_build_add_fastq_host_parsed(self._h, data, len(data), 1 if final else 0, C.byref(used)))
         return used.value
 
+    def add_fasta(self, data):
+        """every canonical k-mer of a FASTA buffer, quality bit set (contaminant set input,
+        error_correct_reads.cc:86-90)"""
+        data = bytes(data)
+        check(lib.qh_build_add_fasta(self._h, data, len(data)))
+
     def add_mers_device(self, dev_ptr, n):
         check(lib.qh_build_add_mers_device(self._h, C.c_void_p(dev_ptr), n))
 
@@ -167,6 +173,21 @@ class HashWithQuality:
             pass
 
 
+def poisson_term(lam, i):
+    """double poisson_term(double lambda, unsigned int i) (error_correct_reads.cc:53-61)"""
+    return lib.qh_poisson_term(lam, i)
+
+
+def contaminant_database(fasta_path, k, device=0):
+    """contaminant_database (error_correct_reads.cc:83-99,692-708) built from FASTA at mer
+    length k; use .is_member() or DatabaseQuery.lookup_with_contaminant()."""
+    q = C.c_void_p()
+    st = lib.qh_contaminant_open_fasta(C.byref(q), str(fasta_path).encode(), k, device)
+    if st != _lib.QH_OK:
+        raise RuntimeError(_lib.last_error())
+    return DatabaseQuery(_handle=q)
+
+
 class DatabaseQuery:
     """database_query(filename, no_mmap=false) (mer_database.hpp:270)."""
 
@@ -227,6 +248,31 @@ class DatabaseQuery:
         d, t = C.c_uint64(), C.c_uint64()
         check(lib.qh_query_stats(self._q, C.byref(d), C.byref(t)))
         return d.value, t.value
+
+    def poisson_cutoff(self, collision_prob, poisson_threshold):
+        """compute_poisson_cutoff(vals(), collision_prob, poisson_threshold)
+        (error_correct_reads.cc:650-674)"""
+        c = C.c_uint()
+        check(lib.qh_query_poisson_cutoff(self._q, collision_prob, poisson_threshold, C.byref(c)))
+        return c.value
+
+    def is_member(self, mers):
+        """contaminant_database::is_contaminant (error_correct_reads.cc:94), batched"""
+        m, pm = _u64(np.atleast_1d(mers))
+        flags = np.empty(m.size, dtype=np.uint8)
+        check(lib.qh_query_is_member_batch(self._q, pm, m.size, flags.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return flags.astype(bool)
+
+    def lookup_with_contaminant(self, contaminant, mers):
+        """database lookup + is_contaminant of the same canonical mers in one pass
+        (error_correct_reads.cc:348,390,620) -> (values, flags)"""
+        m, pm = _u64(np.atleast_1d(mers))
+        out = np.empty(m.size, dtype=np.uint64)
+        flags = np.empty(m.size, dtype=np.uint8)
+        check(lib.qh_query_batch_contaminant(self._q, contaminant._q, pm, m.size,
+                                             out.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                             flags.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out, flags.astype(bool)
 
     def histo(self):
         h = np.zeros((1001, 2), dtype=np.uint64)

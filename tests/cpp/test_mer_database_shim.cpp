@@ -71,12 +71,14 @@ static void test_sequence(const database_query& hash, const std::string& seq, co
   }
 }
 
-// the forward_mer shape get_best_alternatives is instantiated with (src/kmer.hpp:70-89)
+// the forward_mer shape get_best_alternatives is instantiated with (src/kmer.hpp:70-89).
+// canonical() is the identity here: like upstream's, this test stores the mers as they come,
+// not canonicalized.
 struct fwd_mer {
   mer_dna f;
   int code(int i) const { return f.code(i); }
   void replace(int i, int x) { f.replace(i, x); }
-  mer_dna canonical() const { return f.get_canonical(); }
+  mer_dna canonical() const { return f; }
 };
 
 int main(int argc, char* argv[]) {

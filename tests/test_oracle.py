@@ -1,6 +1,7 @@
 """The CPU oracle against the reference's own known answers
 (unit_tests/test_mer_database.cc:115-120), the hand-derived fixtures of
 tests/golden/  and two independent models. CPU only."""
+import os
 import numpy as np
 import pytest
 
@@ -154,3 +155,66 @@ def test_lookup_semantics():
     assert int(h.sum()) == len(table)
     for x in set(table.values()):
         assert h[min(x >> 1, 1000), x & 1] == sum(1 for y in table.values() if y == x)
+
+
+# ---- "next" rows: Poisson cutoff and the contaminant set --------------------------------
+def test_poisson_term_known_answers():
+    """error_correct_reads.cc:53-61 against values worked by hand: exact branch (i < 11) is
+    e^-l l^i / i!; Stirling branch is within 1/(12 i) of it."""
+    import math
+    for lam, i in [(0.1, 0), (0.1, 2), (0.1, 3), (0.1, 4), (2.5, 7), (12.0, 10)]:
+        want = math.exp(-lam) * lam ** i / math.factorial(i)
+        assert po.poisson_term(lam, i) == pytest.approx(want, rel=1e-14)
+    assert po.poisson_term(0.1, 2) == pytest.approx(0.0045241870901797976, rel=1e-13)
+    for lam, i in [(12.0, 11), (12.0, 15), (3.0, 40)]:
+        exact = math.exp(-lam) * lam ** i / math.factorial(i)
+        st = po.poisson_term(lam, i)
+        assert exact < st < exact * (1 + 1.0 / (11 * i))  # Stirling overestimates by ~1/(12 i)
+
+
+def test_poisson_cutoff_known_answers():
+    """error_correct_reads.cc:660-667 with the driver's defaults (quorum.in: apriori error rate
+    0.01, poisson threshold 1e-6 => collision_prob 0.01/3, threshold 1e-4): coverage 30 gives
+    lambda 0.1; terms 4.5e-3 (x=2), 1.5e-4 (x=3), 3.8e-6 (x=4) -> first below 1e-4 is x=4 -> 5."""
+    assert po.poisson_cutoff_from(1000, 30000, 0.01 / 3, 1e-6 / 0.01) == 5
+    # lambda = 1: terms e^-1/x! = 0.184, 0.0613, 0.0153, 3.07e-3, 5.1e-4, 7.3e-5 (x=7) -> 8
+    assert po.poisson_cutoff_from(1, 300, 0.01 / 3, 1e-4) == 8
+    # threshold never reached within x < 1000 -> 0 (:667)
+    assert po.poisson_cutoff_from(1, 1, 0.5, 0.0) == 0
+    db = po.OracleDB(1 << 10, 5, 7)
+    for m, n in [(1, 30), (7, 30), (9, 30)]:
+        for _ in range(n):
+            db.add(m, 1)
+    for _ in range(50):
+        db.add(11, 0)  # low-quality mers do not enter the coverage estimate (:655)
+    assert db.stats() == (3, 90)
+    assert db.poisson_cutoff(0.01 / 3, 1e-4) == 5
+
+
+def test_contaminant_set_from_adapter_fasta():
+    """The reference's data/adapter.fa (copied as a data fixture to tests/golden/adapter.fa):
+    the set must equal every canonical k-mer window of every record, computed here in pure
+    Python. 'parity unpinned' against upstream's `jellyfish count -C` dump, which cannot be
+    produced in this image."""
+    path = os.path.join(os.path.dirname(__file__), "golden", "adapter.fa")
+    data = open(path, "rb").read()
+    k = 24
+    want = set()
+    inst = 0
+    for rec in data.split(b">")[1:]:
+        seq = b"".join(rec.split(b"\n")[1:])
+        for m, _ in window_kmers(seq, b"I" * len(seq), k, 0):
+            want.add(m)
+            inst += 1
+    db = po.OracleDB(1 << 15, k, 1)
+    assert db.add_fasta(data) == inst
+    mers, vals = db.sorted_dump()
+    assert mers.tolist() == sorted(want)
+    assert (vals & np.uint64(1)).all()
+    # multi-line sequences and an N: same set as the joined line
+    db2 = po.OracleDB(1 << 8, 4, 1)
+    db2.add_fasta(b">a desc\nACGTA\nCGNAC\nGTT\n>b\nAC\n>c\nTTTTT")
+    exp = {m for m, _ in window_kmers(b"ACGTACGNACGTT", b"I" * 13, 4, 0)} | {m for m, _ in window_kmers(b"TTTTT", b"IIIII", 4, 0)}
+    assert set(db2.dump()[0].tolist()) == exp
+    with pytest.raises(ValueError, match="Unsupported format"):
+        db2.add_fasta(b"ACGT\n")
