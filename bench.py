@@ -142,7 +142,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if world == 1 and os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(pmc))["per_kernel_hbm_bytes_per_launch"].get(knames[dom])
             except Exception:
                 traffic = None
         out = {

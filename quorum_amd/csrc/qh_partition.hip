@@ -423,12 +423,17 @@ void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsign
 // wave-instruction therefore carries 64 live lanes.
 #define QW_RING 192  // items per wave ring (1.5 KiB)
 
+// NARROW: value and probe fields lie in the low 32 bits of the slot (vbits + pbits <= 32, true
+// for every -b up to 24 at -p 126). Probing then only ever changes the low half of the word a
+// lane offers, so the chain state is 32-bit and the round is ~25 VALU instructions. The kernel
+// is VALU-issue bound (16-lane SIMDs, 4 waves each), so instructions per round are what count:
+// ring bookkeeping is kept wave-uniform in SGPRs and the round is written without branches.
+template <bool NARROW>
 __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restrict__ table, const qh_geom g,
                                                              const uint64_t* __restrict__ items, uint64_t cap,
                                                              const unsigned long long* __restrict__ counts,
                                                              int table_dirty, uint64_t* __restrict__ spill,
-                                                             uint64_t spill_cap, qh_meta* __restrict__ meta,
-                                                             int ablate) {
+                                                             uint64_t spill_cap, qh_meta* __restrict__ meta) {
   __shared__ uint64_t win[1u << QH_WINDOW_BITS];
   __shared__ uint64_t ring[QP_WAVES][QW_RING];
   __shared__ uint32_t wnew[QP_WAVES];
@@ -436,7 +441,8 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
   uint64_t n = counts[w];
   if (n > cap) n = cap;
   if (n == 0) return;  // nothing to add: the window stays as it is
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // this wave's segment of the bucket
   const uint32_t seg = (uint32_t)((n + QP_WAVES - 1) / QP_WAVES);
   const uint32_t s0 = (uint32_t)(((uint64_t)wave * seg) < n ? (uint64_t)wave * seg : n);
@@ -460,14 +466,17 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
   const int gsize = g.lsize + g.shard_bits;
   const uint32_t wmask = (1u << QH_WINDOW_BITS) - 1;
   const uint64_t vkeep = ~g.vmask, one_probe = 1ull << g.vbits;
+  const uint32_t vkeep_lo = (uint32_t)vkeep, vmask_lo = (uint32_t)g.vmask, one_probe_lo = (uint32_t)one_probe;
+  const uint32_t maxv_lo = (uint32_t)g.max_val;
   uint64_t* myring = ring[wave];
   uint32_t head = 0, tail = 0;          // items dealt / items in the ring so far (wave-uniform)
   uint32_t head_mod = 0, tail_mod = 0;  // the same modulo QW_RING
   uint32_t n_new = 0;
   // chain state
   bool live = false;
-  uint64_t v = 0, want = 0, cmp = 0, nw = 0;
-  uint32_t pos = 0, left = 0, fresh = 0;
+  uint64_t v = 0, want = 0, cmp = 0, nw = 0;                 // wide form
+  uint32_t want_lo = 0, want_hi = 0, cmp_lo = 0, nw_lo = 0;  // narrow form
+  uint32_t pos = 0, left = 0, q = 0;
 
   for (;;) {
     uint32_t avail = tail - head;
@@ -491,6 +500,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
     __builtin_amdgcn_wave_barrier();
     // deal items to idle lanes
     const uint64_t need = __ballot(!live);
+    if (need == ~0ull && avail == 0 && !pending && head == seg_n) break;  // all idle, nothing left to deal
     if (need && avail) {
       const uint32_t cnt = (uint32_t)__popcll((unsigned long long)need);
       const uint32_t give = cnt < avail ? cnt : avail;
@@ -504,58 +514,86 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
         // want = (remainder | probe+1) << vbits: our key's slot word at this probe with a zero value
         want = (((gsize >= 64 ? 0 : (h >> gsize)) << g.pbits) | 1) << g.vbits;
         left = (uint32_t)g.max_reprobe;  // probes left after this one
-        fresh = (v & 1) ? 3u : 2u;       // value of a new entry (mer_database.hpp:105-110 from 0)
-        cmp = 0;
-        nw = want | fresh;
+        q = (uint32_t)v & 1u;            // a new entry is 2 | q (mer_database.hpp:105-110 from 0)
+        if (NARROW) {
+          want_lo = (uint32_t)want;
+          want_hi = (uint32_t)(want >> 32);
+          cmp_lo = 0;
+          nw_lo = want_lo | 2u | q;
+        } else {
+          cmp = 0;
+          nw = want | 2u | q;
+        }
         live = true;
       }
       head += give;
       head_mod += give;
       if (head_mod >= QW_RING) head_mod -= QW_RING;
-    } else if (need == ~0ull && !pending && head == seg_n) {
-      break;  // every lane idle, nothing left to deal
     }
-    if (ablate & 1) {  // timing-only build (QH_ABLATE): no insertion
-      n_new += (uint32_t)v;
-      live = false;
-      continue;
-    }
-    // one round
+    // one round: a single compare-and-swap per live lane
     if (live) {
-      const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&win[pos]), (unsigned long long)cmp,
-                                      (unsigned long long)nw);
-      if (prev == cmp) {                          // the swap happened
-        n_new += cmp == 0;
-        live = false;
-      } else if ((prev & vkeep) == want) {        // our key lives here: update round
-        uint64_t nv;
-        if (!qh_update_val(prev & g.vmask, fresh & 1u, g.max_val, &nv)) {
-          live = false;                           // saturated / LQ instance of an HQ mer
-        } else {
-          cmp = prev;
-          nw = want | nv;
+      if (NARROW) {
+        const uint32_t cmp_hi = cmp_lo ? want_hi : 0u;
+        const uint64_t c = ((uint64_t)cmp_hi << 32) | cmp_lo;
+        const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&win[pos]), (unsigned long long)c,
+                                        (unsigned long long)(((uint64_t)want_hi << 32) | nw_lo));
+        const uint32_t plo = (uint32_t)prev, phi = (uint32_t)(prev >> 32);
+        const bool swapped = prev == c;
+        const bool match = ((plo & vkeep_lo) == want_lo) & (phi == want_hi);  // our key lives here
+        const uint32_t pv = plo & vmask_lo, phq = pv & 1u;
+        // mer_database.hpp:102-111 on the value found
+        const bool promote = phq < q;
+        const bool can = promote | (((pv >> 1) != maxv_lo) & (phq == q));
+        const uint32_t nv = promote ? 3u : pv + 2u;
+        n_new += (uint32_t)(swapped & (cmp_lo == 0));
+        const bool upd = !swapped & match & can;  // update round next
+        const bool probe = !swapped & !match;     // another key: next probe
+        if (probe && left == 0) {                 // reprobe limit: leave it to the direct path
+          const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(&meta->spill_count), 1ull);
+          if (at < spill_cap) spill[at] = v;
+          else meta->ovf_lost = 1;
         }
-      } else if (left == 0) {                     // reprobe limit: leave it to the direct path
-        const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(&meta->spill_count), 1ull);
-        if (at < spill_cap) spill[at] = v;
-        else meta->ovf_lost = 1;
-        live = false;
-      } else {                                    // another key: next probe, claim round again
-        --left;
-        pos = (pos + 1) & wmask;
-        want += one_probe;
-        cmp = 0;
-        nw = want | fresh;
+        const bool go = probe & (left != 0);
+        pos = go ? (pos + 1) & wmask : pos;
+        left -= (uint32_t)go;
+        want_lo += go ? one_probe_lo : 0u;
+        cmp_lo = upd ? plo : 0u;
+        nw_lo = want_lo | (upd ? nv : (2u | q));
+        live = upd | go;
+      } else {
+        const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&win[pos]), (unsigned long long)cmp,
+                                        (unsigned long long)nw);
+        if (prev == cmp) {                          // the swap happened
+          n_new += cmp == 0;
+          live = false;
+        } else if ((prev & vkeep) == want) {        // our key lives here: update round
+          uint64_t nv;
+          if (!qh_update_val(prev & g.vmask, q, g.max_val, &nv)) {
+            live = false;                           // saturated / LQ instance of an HQ mer
+          } else {
+            cmp = prev;
+            nw = want | nv;
+          }
+        } else if (left == 0) {                     // reprobe limit: leave it to the direct path
+          const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(&meta->spill_count), 1ull);
+          if (at < spill_cap) spill[at] = v;
+          else meta->ovf_lost = 1;
+          live = false;
+        } else {                                    // another key: next probe, claim round again
+          --left;
+          pos = (pos + 1) & wmask;
+          want += one_probe;
+          cmp = 0;
+          nw = want | 2u | q;
+        }
       }
     }
   }
   n_new = wave_sum_u32(n_new);
   if (lane == 0) wnew[wave] = n_new;
   __syncthreads();
-  if (!(ablate & 2)) {
 #pragma unroll
-    for (uint32_t i = 0; i < nvec / QP_THREADS; ++i) tw[i * QP_THREADS + tid] = lw[i * QP_THREADS + tid];
-  }
+  for (uint32_t i = 0; i < nvec / QP_THREADS; ++i) tw[i * QP_THREADS + tid] = lw[i * QP_THREADS + tid];
   if (tid == 0) {
     uint32_t t = 0;
     for (int i = 0; i < QP_WAVES; ++i) t += wnew[i];
@@ -566,7 +604,10 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
 void qh_launch_window_build(uint64_t* table, const qh_geom& g, const uint64_t* items, uint64_t cap,
                             const unsigned long long* counts, uint32_t n_windows, int table_dirty, uint64_t* spill,
                             uint64_t spill_cap, qh_meta* meta, hipStream_t s) {
-  static const int ablate = getenv("QH_ABLATE") ? atoi(getenv("QH_ABLATE")) : 0;  // timing experiments only
-  hipLaunchKernelGGL(k_window_build, dim3(n_windows), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
-                     table_dirty, spill, spill_cap, meta, ablate);
+  if (g.vbits + g.pbits <= 32)
+    hipLaunchKernelGGL(k_window_build<true>, dim3(n_windows), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
+                       table_dirty, spill, spill_cap, meta);
+  else
+    hipLaunchKernelGGL(k_window_build<false>, dim3(n_windows), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
+                       table_dirty, spill, spill_cap, meta);
 }
