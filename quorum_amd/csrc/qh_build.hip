@@ -138,7 +138,7 @@ extern "C" void qh_build_destroy(qh_build* h) {
   if (!h) return;
   hipError_t e = hipSetDevice(h->device); (void)e;
   if (h->stream) { e = hipStreamSynchronize(h->stream); (void)e; }
-  void* ptrs[] = {h->table, h->d_meta, h->d_chunk, h->d_recs, h->d_tiles, h->d_ovf[0], h->d_ovf[1], h->d_items, h->d_shard_counts, h->d_blkprefix, h->d_rbsums, h->d_blkdesc,
+  void* ptrs[] = {h->table, h->d_meta, h->d_chunk, h->d_recs, h->d_tiles, h->d_ovf[0], h->d_ovf[1], h->d_items, h->d_shard_counts, h->d_blkprefix, h->d_rbsums, h->d_blkdesc, h->d_segdesc, h->d_planes,
                   h->d_bins[0], h->d_bins[1], h->d_bin_counts[0], h->d_bin_counts[1]};
   for (void* p : ptrs) if (p) { e = hipFree(p); (void)e; }
   if (h->h_meta) { e = hipHostFree(h->h_meta); (void)e; }
@@ -314,10 +314,24 @@ static bool use_partition(const qh_build* h, size_t max_items) {
   return wid_bits >= 8 && max_items >= (((size_t)1 << h->g.lsize) >> 3);
 }
 
+// device arrays of the FASTQ source for a chunk of at most rec_cap records / max_bases bases
+static int fastq_aux(qh_build* h, size_t rec_cap, size_t max_bases, qh_fastq_aux* a, size_t* max_blocks) {
+  const size_t blocks = max_bases / 64 + rec_cap, segs = max_bases / QH_SEG_KMERS + rec_cap;
+  int rc;
+  if ((rc = ensure((void**)&h->d_rbsums, &h->rbsums_cap, (2 * (rec_cap / 1024 + 2) + 2) * 4, "record block sums"))) return rc;
+  if ((rc = ensure((void**)&h->d_blkprefix, &h->blkprefix_cap, (rec_cap + 2) * 4, "record block prefix"))) return rc;
+  if ((rc = ensure((void**)&h->d_blkdesc, &h->blkdesc_cap, (blocks + 2) * 16, "block descriptors"))) return rc;
+  if ((rc = ensure((void**)&h->d_segdesc, &h->segdesc_cap, (segs + 2) * 8, "segment descriptors"))) return rc;
+  if ((rc = ensure((void**)&h->d_planes, &h->planes_cap, (blocks + 2) * 32, "bit planes"))) return rc;
+  *a = {h->d_rbsums, h->d_blkprefix, h->d_blkdesc, h->d_segdesc, h->d_planes};
+  *max_blocks = blocks;
+  return QH_OK;
+}
+
 struct part_source {
   const uint8_t* fastq = nullptr;    // FASTQ chunk whose record table is in h->d_recs
   size_t rec_cap = 0;
-  size_t max_blocks = 0;             // upper bound of the chunk's 64-base blocks
+  size_t max_bases = 0;              // upper bound of the chunk's bases
   const uint64_t* items = nullptr;   // or an item list
   size_t n_items = 0;
   int hashed = 0;
@@ -357,14 +371,17 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
   else win_dst.out_bin_shift = 0;
   const int check_owner = g.shard_bits > 0;
 
-  timing_begin(h, 1);
   if (src.fastq) {
-    if ((rc = ensure((void**)&h->d_rbsums, &h->rbsums_cap, (src.rec_cap / 1024 + 4) * 4, "record block sums"))) return rc;
-    if ((rc = ensure((void**)&h->d_blkprefix, &h->blkprefix_cap, (src.rec_cap + 2) * 4, "record block prefix"))) return rc;
-    if ((rc = ensure((void**)&h->d_blkdesc, &h->blkdesc_cap, (src.max_blocks + 2) * 16, "block descriptors"))) return rc;
-    qh_launch_rec_blocks(h->d_recs, (uint32_t)src.rec_cap, h->d_meta, h->d_rbsums, h->d_blkprefix, h->d_blkdesc, h->stream);
-    qh_launch_partition_fastq(src.fastq, h->d_recs, h->d_blkprefix, h->d_blkdesc, h->d_meta, g, l1_dst, check_owner, h->stream);
+    qh_fastq_aux aux;
+    size_t max_blocks;
+    if ((rc = fastq_aux(h, src.rec_cap, src.max_bases, &aux, &max_blocks))) return rc;
+    timing_begin(h, 0);
+    qh_launch_fastq_prepare(src.fastq, h->d_recs, (uint32_t)src.rec_cap, h->d_meta, g, aux, max_blocks, h->stream);
+    timing_end(h, 0);
+    timing_begin(h, 1);
+    qh_launch_partition_fastq(aux, (uint32_t)src.rec_cap, h->d_meta, g, l1_dst, check_owner, h->stream);
   } else {
+    timing_begin(h, 1);
     qh_launch_partition_items(src.items, src.n_items, nullptr, 1, src.n_items, src.hashed, h->d_meta, g, l1_dst,
                               check_owner, 1, h->stream);
   }
@@ -405,7 +422,7 @@ extern "C" int qh_build_add_fastq_device(qh_build* h, const void* dev_buf, size_
     part_source src;
     src.fastq = (const uint8_t*)dev_buf;
     src.rec_cap = rec_cap;
-    src.max_blocks = len / 64 + rec_cap;
+    src.max_bases = len / 2;
     if ((rc = run_partitioned(h, src, len / 2))) return rc;
   } else {
     timing_begin(h);
@@ -456,7 +473,7 @@ static int submit_records(qh_build* h, const uint8_t* dev_buf, const qh_record* 
     part_source src;
     src.fastq = dev_buf;
     src.rec_cap = nrec;
-    src.max_blocks = max_items / 64 + nrec;
+    src.max_bases = max_items;
     if ((rc = run_partitioned(h, src, max_items))) return rc;
   } else {
     timing_begin(h);
@@ -728,15 +745,14 @@ extern "C" int qh_build_extract_partitioned_device(qh_build* h, const void* dev_
   if ((rc = ensure((void**)&h->d_tiles, &h->tile_cap, (ntiles + 1) * 4, "tile counts"))) return rc;
   if ((rc = ensure((void**)&h->d_recs, &h->rec_cap, rec_cap * 16, "record table"))) return rc;
   qh_launch_index_fastq((const uint8_t*)dev_buf, len, h->d_tiles, h->d_recs, (uint32_t)rec_cap, h->d_meta, h->stream);
-  const size_t max_blocks = len / 64 + rec_cap;
-  if ((rc = ensure((void**)&h->d_rbsums, &h->rbsums_cap, (rec_cap / 1024 + 4) * 4, "record block sums"))) return rc;
-  if ((rc = ensure((void**)&h->d_blkprefix, &h->blkprefix_cap, (rec_cap + 2) * 4, "record block prefix"))) return rc;
-  if ((rc = ensure((void**)&h->d_blkdesc, &h->blkdesc_cap, (max_blocks + 2) * 16, "block descriptors"))) return rc;
-  qh_launch_rec_blocks(h->d_recs, (uint32_t)rec_cap, h->d_meta, h->d_rbsums, h->d_blkprefix, h->d_blkdesc, h->stream);
+  qh_fastq_aux aux;
+  size_t max_blocks;
+  if ((rc = fastq_aux(h, rec_cap, len / 2, &aux, &max_blocks))) return rc;
+  qh_launch_fastq_prepare((const uint8_t*)dev_buf, h->d_recs, (uint32_t)rec_cap, h->d_meta, h->g, aux, max_blocks, h->stream);
   // bucket = owner shard = low shard_bits of the hash; a bucket that overflows is an error here
   qh_part_dst dst = {dev_out, cap_per_shard, (unsigned long long*)dev_counts, 0, h->g.shard_bits, 0, nullptr, 0};
   timing_begin(h, 1);
-  qh_launch_partition_fastq((const uint8_t*)dev_buf, h->d_recs, h->d_blkprefix, h->d_blkdesc, h->d_meta, h->g, dst, 0, h->stream);
+  qh_launch_partition_fastq(aux, (uint32_t)rec_cap, h->d_meta, h->g, dst, 0, h->stream);
   timing_end(h, 1);
   QH_HIP(hipGetLastError());
   // format / capacity verdict of this call

@@ -99,6 +99,20 @@ __device__ __forceinline__ uint32_t window_top32(uint64_t cur, uint64_t prev, in
   return (uint32_t)(((cur << (63 - lane)) | ((prev >> lane) >> 1)) >> 32);
 }
 
+// min(m, rm) of create_database.cc:86 on plane forms (m0/m1 = low/high code bits of the forward
+// mer, r0/r1 of its reverse complement, base i at bit i), returned as a PLANE KEY (qh_pkey form).
+// m < rm as 2-bit packed integers is decided at the most significant base where they differ:
+// with that base shifted to bit 31, forward wins iff its high bit is 0 where the high bits
+// differ, else iff its low bit is 0.
+__device__ __forceinline__ uint64_t qh_canonical_pkey(uint32_t m0, uint32_t m1, uint32_t r0, uint32_t r1, int k) {
+  const uint32_t d1 = m1 ^ r1, d = (m0 ^ r0) | d1;
+  const int c = __clz((int)d) & 31;  // d == 0 (palindrome): either
+  const uint32_t sel = ((int32_t)(d1 << c) < 0) ? m1 : m0;
+  const bool fwd = (int32_t)(sel << c) >= 0;
+  const uint32_t c0 = fwd ? m0 : r0, c1 = fwd ? m1 : r1;
+  return (uint64_t)c0 | ((uint64_t)c1 << k);
+}
+
 // Emits the canonical k-mer ending at this lane's base as a PLANE KEY (qh_pkey form: low code
 // bits | high code bits << k); the 2-bit interleaved form is never built on this path.
 __device__ __forceinline__ bool qh_lane_kmer(const qh_planes& cur, const qh_planes& prev, int lane, int k,
@@ -112,18 +126,7 @@ __device__ __forceinline__ bool qh_lane_kmer(const qh_planes& cur, const qh_plan
   const uint32_t m0 = __builtin_bitreverse32(x0) & kones, m1 = __builtin_bitreverse32(x1) & kones;
   // reverse complement: base i = 3 - (forward base k-1-i) -> complemented window, oldest base lowest
   const uint32_t r0 = (~x0) >> drop, r1 = (~x1) >> drop;
-  // m < rm as 2-bit packed integers (create_database.cc:86): decided at the most significant base
-  // where they differ, comparing (high bit, low bit) there
-  const uint32_t d = (m0 ^ r0) | (m1 ^ r1);
-  bool fwd = true;  // palindrome: either
-  if (d) {
-    const int t = 31 - __clz((int)d);
-    const uint32_t mv = (((m1 >> t) & 1u) << 1) | ((m0 >> t) & 1u);
-    const uint32_t rv = (((r1 >> t) & 1u) << 1) | ((r0 >> t) & 1u);
-    fwd = mv < rv;
-  }
-  const uint32_t c0 = fwd ? m0 : r0, c1 = fwd ? m1 : r1;
-  *pkey = (uint64_t)c0 | ((uint64_t)c1 << k);
+  *pkey = qh_canonical_pkey(m0, m1, r0, r1, k);
   return true;
 }
 

@@ -60,14 +60,26 @@ struct qh_part_dst {
   uint64_t* spill;                 // items beyond a bucket's capacity (meta->spill_count)
   uint64_t spill_cap;
 };
-// record table -> exclusive prefix of 64-base blocks (blk_prefix[nrec] = total);
-// tile_sums needs ceil(rec_cap/1024)+1 words
-// and the descriptor of every block (blk_desc, 16 bytes per block)
-void qh_launch_rec_blocks(const uint4* recs, uint32_t rec_cap, const qh_meta* meta, uint32_t* tile_sums,
-                          uint32_t* blk_prefix, uint4* blk_desc, hipStream_t s);
-void qh_launch_partition_fastq(const uint8_t* buf, const uint4* recs, const uint32_t* blk_prefix,
-                               const uint4* blk_desc, qh_meta* meta,
-                               const qh_geom& g, const qh_part_dst& d, int check_owner, hipStream_t s);
+// Per-chunk device arrays of the FASTQ source (sizes for rec_cap records, max_blocks 64-base
+// blocks, max_segs segments of QH_SEG_KMERS k-mers):
+//   tile_sums  2 * (ceil(rec_cap/1024) + 1) words   scan scratch; holds the block / segment totals
+//   blk_prefix rec_cap + 1 words                     exclusive prefix of blocks per record
+//   blk_desc   max_blocks x 16 B                     {seq offset, qual offset, bases, index in read}
+//   seg_desc   max_segs x 8 B                        {plane block, bit offset | k-mers << 8}
+//   planes     (max_blocks + 2) x 32 B               valid / high-quality / code bit 0 / code bit 1
+#define QH_SEG_KMERS 12
+struct qh_fastq_aux {
+  uint32_t* tile_sums;
+  uint32_t* blk_prefix;
+  uint4* blk_desc;
+  uint2* seg_desc;
+  uint64_t* planes;
+};
+// record table -> prefixes, descriptors and the bit planes of the chunk (4 kernels)
+void qh_launch_fastq_prepare(const uint8_t* buf, const uint4* recs, uint32_t rec_cap, const qh_meta* meta,
+                             const qh_geom& g, const qh_fastq_aux& a, uint64_t max_blocks, hipStream_t s);
+void qh_launch_partition_fastq(const qh_fastq_aux& a, uint32_t rec_cap, qh_meta* meta, const qh_geom& g,
+                               const qh_part_dst& d, int check_owner, hipStream_t s);
 void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsigned long long* in_counts,
                                uint32_t n_in_buckets, uint64_t in_n, int in_hashed, qh_meta* meta, const qh_geom& g,
                                const qh_part_dst& d, int check_owner, int count_instances, hipStream_t s);

@@ -28,26 +28,47 @@
 #define QP_MAX_BINS 4096
 #define QP_NONE (~0ull)
 
-// ------------------------------------------- blocks-per-record prefix (3 small kernels)
+// ------------------------- per-record prefixes, descriptors and bit planes of a FASTQ chunk
+//
+// A record of `len` bases owns ceil(len/64) plane BLOCKS (32 bytes each: the valid, high-quality,
+// code-bit-0 and code-bit-1 planes of 64 consecutive positions) and ceil((len-k+1)/QP_SEG)
+// SEGMENTS of up to QP_SEG consecutive k-mers, the unit of work of one extraction lane.
 
 #define RB_TILE 1024  // records per scan tile
+#define QP_SEG 12     // k-mers per segment (= items a lane keeps in registers per tile)
 
-__global__ __launch_bounds__(256) void k_rec_blocks_sum(const uint4* __restrict__ recs, const qh_meta* __restrict__ meta,
-                                                        uint32_t* __restrict__ tile_sums) {
-  __shared__ uint32_t ws[4];
-  const uint32_t nrec = meta->format_err ? 0 : meta->nrec;
-  const uint32_t base = blockIdx.x * RB_TILE;
-  uint32_t s = 0;
-  for (uint32_t r = base + threadIdx.x; r < base + RB_TILE && r < nrec; r += 256) s += (recs[r].y + 63) >> 6;
-  s = wave_sum_u32(s);
-  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) tile_sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+__device__ __forceinline__ uint32_t rec_nblocks(uint32_t len) { return (len + 63) >> 6; }
+__device__ __forceinline__ uint32_t rec_nsegs(uint32_t len, uint32_t k) {
+  return len >= k ? (len - k + 1 + QP_SEG - 1) / QP_SEG : 0;
 }
 
-// exclusive scan of n u32 values in place by one workgroup; the total goes to *total
-__global__ __launch_bounds__(1024) void k_scan_u32(uint32_t* __restrict__ v, uint32_t n, uint32_t* __restrict__ total) {
+// tile_sums: [0, ntiles] block sums (total at [ntiles]), [ntiles+1, 2*ntiles+1] segment sums
+__global__ __launch_bounds__(256) void k_rec_blocks_sum(const uint4* __restrict__ recs, const qh_meta* __restrict__ meta,
+                                                        uint32_t* __restrict__ tile_sums, uint32_t ntiles, uint32_t k) {
+  __shared__ uint32_t ws[2][4];
+  const uint32_t nrec = meta->format_err ? 0 : meta->nrec;
+  const uint32_t base = blockIdx.x * RB_TILE;
+  uint32_t s = 0, t = 0;
+  for (uint32_t r = base + threadIdx.x; r < base + RB_TILE && r < nrec; r += 256) {
+    const uint32_t len = recs[r].y;
+    s += rec_nblocks(len);
+    t += rec_nsegs(len, k);
+  }
+  s = wave_sum_u32(s);
+  t = wave_sum_u32(t);
+  if ((threadIdx.x & 63) == 0) { ws[0][threadIdx.x >> 6] = s; ws[1][threadIdx.x >> 6] = t; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    tile_sums[blockIdx.x] = ws[0][0] + ws[0][1] + ws[0][2] + ws[0][3];
+    tile_sums[ntiles + 1 + blockIdx.x] = ws[1][0] + ws[1][1] + ws[1][2] + ws[1][3];
+  }
+}
+
+// exclusive scan of n u32 values in place by one workgroup; the total goes to v[n]. Workgroup b
+// scans the array that starts at v + b * (n + 1).
+__global__ __launch_bounds__(1024) void k_scan_u32(uint32_t* __restrict__ v0, uint32_t n) {
   __shared__ uint32_t part[1024];
+  uint32_t* v = v0 + (size_t)blockIdx.x * (n + 1);
   const uint32_t per = (n + 1023) / 1024;
   const uint32_t b = threadIdx.x * per;
   uint32_t s = 0;
@@ -66,41 +87,40 @@ __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t* __restrict__ v, uin
     v[i] = run;
     run += c;
   }
-  if (threadIdx.x == 1023) *total = part[1023];
+  if (threadIdx.x == 1023) v[n] = part[1023];
 }
 
 __global__ __launch_bounds__(256) void k_rec_blocks_apply(const uint4* __restrict__ recs, const qh_meta* __restrict__ meta,
-                                                          const uint32_t* __restrict__ tile_prefix,
-                                                          const uint32_t* __restrict__ total,
-                                                          uint32_t* __restrict__ blk_prefix,
-                                                          uint4* __restrict__ blk_desc) {
-  __shared__ uint32_t wtot[4];
+                                                          const uint32_t* __restrict__ tile_sums, uint32_t ntiles,
+                                                          uint32_t k, uint32_t* __restrict__ blk_prefix,
+                                                          uint4* __restrict__ blk_desc, uint2* __restrict__ seg_desc) {
+  __shared__ uint32_t wtot[2][4];
   const uint32_t nrec = meta->format_err ? 0 : meta->nrec;
   const uint32_t base = blockIdx.x * RB_TILE;
   if (base >= nrec) {
     if (blockIdx.x == 0 && threadIdx.x == 0) blk_prefix[0] = 0;  // nrec == 0
     return;
   }
-  uint32_t run = tile_prefix[blockIdx.x];
+  uint32_t run = tile_sums[blockIdx.x], srun = tile_sums[ntiles + 1 + blockIdx.x];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (uint32_t j = 0; j < RB_TILE; j += 256) {
     const uint32_t r = base + j + threadIdx.x;
     const uint4 rc = r < nrec ? recs[r] : make_uint4(0, 0, 0, 0);
-    const uint32_t c = (rc.y + 63) >> 6;
-    uint32_t inc = c;
+    const uint32_t c = rec_nblocks(rc.y), cs = rec_nsegs(rc.y, k);
+    uint32_t inc = c, sinc = cs;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t x = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += x;
+      const uint32_t x = __shfl_up(inc, o, 64), y = __shfl_up(sinc, o, 64);
+      if (lane >= o) { inc += x; sinc += y; }
     }
-    if (lane == 63) wtot[wv] = inc;
+    if (lane == 63) { wtot[0][wv] = inc; wtot[1][wv] = sinc; }
     __syncthreads();
-    uint32_t wbase = 0, tot = 0;
+    uint32_t wbase = 0, tot = 0, swbase = 0, stot = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      const uint32_t x = wtot[w];
-      if (w < wv) wbase += x;
-      tot += x;
+      const uint32_t x = wtot[0][w], y = wtot[1][w];
+      if (w < wv) { wbase += x; swbase += y; }
+      tot += x; stot += y;
     }
     if (r < nrec) {
       const uint32_t pb = run + wbase + inc - c;
@@ -111,20 +131,74 @@ __global__ __launch_bounds__(256) void k_rec_blocks_apply(const uint4* __restric
         const uint32_t left = rc.y - b * 64;
         blk_desc[pb + b] = make_uint4(rc.x + b * 64, rc.z + b * 64, left < 64 ? left : 64, b);
       }
+      // descriptor of every segment: k-mers [a, a + n) of the read (k-mer i spans positions
+      // i .. i+k-1) = {plane block of position a, (a & 63) | n << 8}
+      const uint32_t ps = srun + swbase + sinc - cs;
+      const uint32_t nk = cs ? rc.y - k + 1 : 0;
+      for (uint32_t b = 0; b < cs; ++b) {
+        const uint32_t a = b * QP_SEG, left = nk - a;
+        seg_desc[ps + b] = make_uint2(pb + (a >> 6), (a & 63) | ((left < QP_SEG ? left : QP_SEG) << 8));
+      }
     }
     run += tot;
+    srun += stot;
     __syncthreads();
   }
-  if (threadIdx.x == 0 && base + RB_TILE >= nrec) blk_prefix[nrec] = *total;
+  if (threadIdx.x == 0 && base + RB_TILE >= nrec) blk_prefix[nrec] = tile_sums[ntiles];
 }
 
-void qh_launch_rec_blocks(const uint4* recs, uint32_t rec_cap, const qh_meta* meta, uint32_t* tile_sums,
-                          uint32_t* blk_prefix, uint4* blk_desc, hipStream_t s) {
+// FASTQ text -> bit planes, create_database.cc:73-84 for 64 bases at a time: a lane per base, the
+// wave's four ballots are the block's planes. Each wave takes QPK_BLOCKS consecutive blocks per
+// round with all their byte loads in flight together.
+#define QPK_BLOCKS 8
+
+__global__ __launch_bounds__(256) void k_pack_planes(const uint8_t* __restrict__ buf, const uint4* __restrict__ blk_desc,
+                                                     const uint32_t* __restrict__ blk_prefix,
+                                                     const qh_meta* __restrict__ meta, uint64_t* __restrict__ planes,
+                                                     int min_qual) {
+  if (meta->format_err) return;
+  const uint32_t nblk = blk_prefix[meta->nrec];
+  const int lane = threadIdx.x & 63;
+  const uint32_t gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+  for (uint64_t b0 = (uint64_t)gw * QPK_BLOCKS; b0 < nblk; b0 += (uint64_t)nw * QPK_BLOCKS) {
+    uint4 d = make_uint4(0, 0, 0, 0);
+    if (lane < QPK_BLOCKS && b0 + lane < nblk) d = blk_desc[b0 + lane];
+    uint8_t bb[QPK_BLOCKS];
+    int8_t qq[QPK_BLOCKS];
+#pragma unroll
+    for (int sl = 0; sl < QPK_BLOCKS; ++sl) {
+      const uint32_t so = __builtin_amdgcn_readlane(d.x, sl), qo = __builtin_amdgcn_readlane(d.y, sl);
+      const uint32_t nv = __builtin_amdgcn_readlane(d.z, sl);
+      const uint32_t l = (uint32_t)lane < nv ? (uint32_t)lane : 0u;
+      bb[sl] = buf[(size_t)so + l];
+      qq[sl] = (int8_t)buf[(size_t)qo + l];
+    }
+#pragma unroll
+    for (int sl = 0; sl < QPK_BLOCKS; ++sl) {
+      const uint32_t nv = __builtin_amdgcn_readlane(d.z, sl);
+      const int code = qh_code(bb[sl]);
+      const bool valid = code >= 0 && (uint32_t)lane < nv;
+      const uint64_t pv = __ballot(valid);
+      const uint64_t ph = __ballot(valid && (int)qq[sl] >= (int)(int8_t)min_qual);  // signed char compare (:81)
+      const uint64_t p0 = __ballot(valid && (code & 1));
+      const uint64_t p1 = __ballot(valid && (code & 2));
+      if (lane < 4 && b0 + sl < nblk) planes[(b0 + sl) * 4 + lane] = lane == 0 ? pv : lane == 1 ? ph : lane == 2 ? p0 : p1;
+    }
+  }
+}
+
+void qh_launch_fastq_prepare(const uint8_t* buf, const uint4* recs, uint32_t rec_cap, const qh_meta* meta,
+                             const qh_geom& g, const qh_fastq_aux& a, uint64_t max_blocks, hipStream_t s) {
   const uint32_t ntiles = (rec_cap + RB_TILE - 1) / RB_TILE;
-  // tile_sums[ntiles] receives the total
-  hipLaunchKernelGGL(k_rec_blocks_sum, dim3(ntiles), dim3(256), 0, s, recs, meta, tile_sums);
-  hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, tile_sums, ntiles, tile_sums + ntiles);
-  hipLaunchKernelGGL(k_rec_blocks_apply, dim3(ntiles), dim3(256), 0, s, recs, meta, tile_sums, tile_sums + ntiles, blk_prefix, blk_desc);
+  hipLaunchKernelGGL(k_rec_blocks_sum, dim3(ntiles), dim3(256), 0, s, recs, meta, a.tile_sums, ntiles, (uint32_t)g.k);
+  hipLaunchKernelGGL(k_scan_u32, dim3(2), dim3(1024), 0, s, a.tile_sums, ntiles);
+  hipLaunchKernelGGL(k_rec_blocks_apply, dim3(ntiles), dim3(256), 0, s, recs, meta, a.tile_sums, ntiles, (uint32_t)g.k,
+                     a.blk_prefix, a.blk_desc, a.seg_desc);
+  uint64_t wgs = (max_blocks + 4 * QPK_BLOCKS - 1) / (4 * QPK_BLOCKS);
+  if (wgs > 256 * 8 * 4) wgs = 256 * 8 * 4;
+  if (wgs < 1) wgs = 1;
+  hipLaunchKernelGGL(k_pack_planes, dim3((unsigned)wgs), dim3(256), 0, s, buf, a.blk_desc, a.blk_prefix, meta, a.planes,
+                     g.min_qual);
 }
 
 // ------------------------------------------------------------- LDS-staged multi-split
@@ -142,11 +216,10 @@ struct qp_params {
   qh_meta* meta;
   int check_owner;     // drop (and count) items whose owner shard is not g.shard_id
   int count_instances; // add emitted items to meta->instances / hq_instances
-  // SRC_FASTQ
-  const uint8_t* buf;
-  const uint4* recs;
-  const uint32_t* blk_prefix;
-  const uint4* blk_desc;
+  // SRC_FASTQ: the chunk as bit planes + segment descriptors (qh_launch_fastq_prepare)
+  const uint64_t* planes;
+  const uint2* seg_desc;
+  const uint32_t* seg_total;
   // SRC_ITEMS: input bucket b = blockIdx.y holds in[b * in_cap ...], in_counts[b] items (or in_n when in_counts == 0)
   const uint64_t* in;
   uint64_t in_cap;
@@ -179,14 +252,13 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
   uint32_t n_inst = 0, n_hq = 0, n_foreign = 0;
 
   uint64_t ntiles;
-  uint32_t nrec = 0, nblk = 0;
+  uint32_t nseg = 0;
   const uint64_t* src = nullptr;
   uint64_t src_n = 0;
   if (SRC == QP_SRC_FASTQ) {
     if (p.meta->format_err) return;
-    nrec = p.meta->nrec;
-    nblk = p.blk_prefix[nrec];
-    ntiles = (nblk + QP_TILE_BLOCKS - 1) / QP_TILE_BLOCKS;
+    nseg = *p.seg_total;
+    ntiles = ((uint64_t)nseg + QP_THREADS - 1) / QP_THREADS;
   } else {
     src = p.in + (uint64_t)blockIdx.y * p.in_cap;
     src_n = p.in_counts ? (uint64_t)p.in_counts[blockIdx.y] : p.in_n;
@@ -197,28 +269,19 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
 
   // Software pipeline over this workgroup's tiles: the inputs of tile t+1 are requested while
   // tile t is sorted and written out (one workgroup per CU: nothing else would hide the latency).
-  // FASTQ: lane s < 13 holds the descriptor of block g0-1+s (slot 0 is the block before the wave's
-  // first one: a k-mer's window reaches k-1 bases back); the 26 byte loads of a tile are issued
-  // together, unconditionally (lanes past a block's end re-read its first byte and are masked when
-  // the planes are formed).
-  uint4 dcur = make_uint4(0, 0, 0, 0), dnext = make_uint4(0, 0, 0, 0);
-  uint8_t bb[QP_BLOCKS_PER_WAVE + 1];
-  int8_t qq[QP_BLOCKS_PER_WAVE + 1];
+  // FASTQ: a lane per segment; its descriptor is fetched two tiles ahead, its two plane blocks
+  // (64 bytes) one tile ahead.
+  uint2 sd_cur = make_uint2(0, 0), sd_next = make_uint2(0, 0);
+  uint4 pl[4];
   uint64_t raw[QP_BLOCKS_PER_WAVE];
-  auto load_desc = [&](uint64_t tile) -> uint4 {
-    const uint64_t gb = tile * QP_TILE_BLOCKS + (uint64_t)wave * QP_BLOCKS_PER_WAVE + lane;  // block + 1
-    if (lane <= QP_BLOCKS_PER_WAVE && gb >= 1 && gb - 1 < nblk) return p.blk_desc[gb - 1];
-    return make_uint4(0, 0, 0, 0);
+  auto load_sdesc = [&](uint64_t tile) -> uint2 {
+    const uint64_t sidx = tile * QP_THREADS + tid;
+    return sidx < nseg ? p.seg_desc[sidx] : make_uint2(0, 0);
   };
-  auto issue_bytes = [&](const uint4& d) {
+  auto issue_planes = [&](const uint2& sd) {
+    const uint4* q = reinterpret_cast<const uint4*>(p.planes) + 2 * (size_t)sd.x;
 #pragma unroll
-    for (int sl = 0; sl <= QP_BLOCKS_PER_WAVE; ++sl) {
-      const uint32_t so = __builtin_amdgcn_readlane(d.x, sl), qo = __builtin_amdgcn_readlane(d.y, sl);
-      const uint32_t nv = __builtin_amdgcn_readlane(d.z, sl);
-      const uint32_t l = (uint32_t)lane < nv ? (uint32_t)lane : 0u;
-      bb[sl] = p.buf[(size_t)so + l];
-      qq[sl] = (int8_t)p.buf[(size_t)qo + l];
-    }
+    for (int i = 0; i < 4; ++i) pl[i] = q[i];
   };
   auto issue_items = [&](uint64_t tile) {
     const uint64_t j0 = tile * QP_TILE_ITEMS + (uint64_t)wave * (QP_BLOCKS_PER_WAVE * 64) + lane;
@@ -229,9 +292,9 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
     }
   };
   if (SRC == QP_SRC_FASTQ) {
-    dcur = load_desc(blockIdx.x);
-    issue_bytes(dcur);
-    dnext = load_desc((uint64_t)blockIdx.x + gridDim.x);
+    sd_cur = load_sdesc(blockIdx.x);
+    issue_planes(sd_cur);
+    sd_next = load_sdesc((uint64_t)blockIdx.x + gridDim.x);
   } else {
     issue_items(blockIdx.x);
   }
@@ -246,39 +309,42 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
     for (int i = 0; i < QP_BLOCKS_PER_WAVE; ++i) it[i] = QP_NONE;
 
     if (SRC == QP_SRC_FASTQ) {
-      qh_planes prev = {0, 0, 0, 0};
+      // create_database.cc:64-92 for the segment's k-mers: no rolling registers, every k-mer is a
+      // k-bit window of the planes. w* hold positions a .. a+63 of the read (bit i = position a+i).
+      const uint32_t o = sd_cur.y & 63u, cnt = (sd_cur.y >> 8) & 63u;
+      if (cnt) {
+        const uint32_t kones = (uint32_t)((1ull << g.k) - 1);
+        auto fun = [&](uint32_t lo0, uint32_t lo1, uint32_t hi0, uint32_t hi1) -> uint64_t {
+          const uint64_t lo = ((uint64_t)lo1 << 32) | lo0, hi = ((uint64_t)hi1 << 32) | hi0;
+          return (lo >> o) | ((hi << 1) << (63 - o));
+        };
+        const uint64_t wv = fun(pl[0].x, pl[0].y, pl[2].x, pl[2].y), wh = fun(pl[0].z, pl[0].w, pl[2].z, pl[2].w);
+        const uint64_t w0 = fun(pl[1].x, pl[1].y, pl[3].x, pl[3].y), w1 = fun(pl[1].z, pl[1].w, pl[3].z, pl[3].w);
+        // forward orientation: bit-reversed planes, aligned so that the newest base of k-mer j sits
+        // at bit QP_SEG-1-j
+        const int sh0 = 64 - g.k - (QP_SEG - 1);
+        const uint64_t f0 = __builtin_bitreverse64(w0) >> sh0, f1 = __builtin_bitreverse64(w1) >> sh0;
 #pragma unroll
-      for (int sl = 0; sl <= QP_BLOCKS_PER_WAVE; ++sl) {
-        const uint32_t nv = __builtin_amdgcn_readlane(dcur.z, sl);
-        const uint32_t jblk = __builtin_amdgcn_readlane(dcur.w, sl);
-        const int code = qh_code(bb[sl]);
-        const bool valid = code >= 0 && (uint32_t)lane < nv;
-        qh_planes cur;
-        cur.v = __ballot(valid);
-        cur.h = __ballot(valid && (int)qq[sl] >= (int)(int8_t)g.min_qual);
-        cur.l0 = __ballot(valid && (code & 1));
-        cur.l1 = __ballot(valid && (code & 2));
-        if (sl > 0 && nv) {
-          if (jblk == 0) prev = qh_planes{0, 0, 0, 0};  // first block of its read
-          uint64_t key;
-          uint32_t q;
-          if (qh_lane_kmer(cur, prev, lane, g.k, &key, &q)) {
-            const uint64_t h = qh_mix(key, g.k);
+        for (int j = 0; j < QP_SEG; ++j) {
+          if ((uint32_t)j < cnt && ((uint32_t)(wv >> j) & kones) == kones) {  // low_len >= k (:85)
+            const uint32_t q = ((uint32_t)(wh >> j) & kones) == kones;         // high_len >= k (:86)
+            const uint32_t r0 = ~(uint32_t)(w0 >> j) & kones, r1 = ~(uint32_t)(w1 >> j) & kones;
+            const uint32_t m0 = (uint32_t)(f0 >> (QP_SEG - 1 - j)) & kones, m1 = (uint32_t)(f1 >> (QP_SEG - 1 - j)) & kones;
+            const uint64_t h = qh_mix(qh_canonical_pkey(m0, m1, r0, r1, g.k), g.k);
             if (p.check_owner && ((uint32_t)h & smask) != (uint32_t)g.shard_id) {
               ++n_foreign;
             } else {
               ++n_inst; n_hq += q;
-              it[sl - 1] = (h << 1) | q;
+              it[j] = (h << 1) | q;
               if (!(p.ablate & 64)) atomicAdd(&cursor[(uint32_t)(h >> p.bin_shift) & p.bin_mask], 1u);
             }
           }
         }
-        prev = cur;
       }
-      // next tile: its bytes now (descriptors arrived an iteration ago), the descriptors after it
-      dcur = dnext;
-      issue_bytes(dcur);
-      dnext = load_desc(tile + 2ull * gridDim.x);
+      // next tile: its planes now (descriptors arrived an iteration ago), the descriptors after it
+      sd_cur = sd_next;
+      issue_planes(sd_cur);
+      sd_next = load_sdesc(tile + 2ull * gridDim.x);
     } else {
 #pragma unroll
       for (int i = 0; i < QP_BLOCKS_PER_WAVE; ++i) {
@@ -385,12 +451,12 @@ static void fill_common(qp_params& p, const qh_part_dst& d, qh_meta* meta, int c
   p.ablate = ablate;
 }
 
-void qh_launch_partition_fastq(const uint8_t* buf, const uint4* recs, const uint32_t* blk_prefix,
-                               const uint4* blk_desc, qh_meta* meta,
-                               const qh_geom& g, const qh_part_dst& d, int check_owner, hipStream_t s) {
+void qh_launch_partition_fastq(const qh_fastq_aux& a, uint32_t rec_cap, qh_meta* meta, const qh_geom& g,
+                               const qh_part_dst& d, int check_owner, hipStream_t s) {
   qp_params p = {};
   fill_common(p, d, meta, check_owner, 1);
-  p.buf = buf; p.recs = recs; p.blk_prefix = blk_prefix; p.blk_desc = blk_desc;
+  p.planes = a.planes; p.seg_desc = a.seg_desc;
+  p.seg_total = a.tile_sums + 2 * ((rec_cap + RB_TILE - 1) / RB_TILE) + 1;
   hipLaunchKernelGGL(k_partition<QP_SRC_FASTQ>, dim3(256), dim3(QP_THREADS), 0, s, p, g);
 }
 
