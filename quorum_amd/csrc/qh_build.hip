@@ -330,6 +330,7 @@ static int fastq_aux(qh_build* h, size_t rec_cap, size_t max_bases, qh_fastq_aux
 
 struct part_source {
   const uint8_t* fastq = nullptr;    // FASTQ chunk whose record table is in h->d_recs
+  size_t fastq_len = 0;              // bytes of that chunk
   size_t rec_cap = 0;
   size_t max_bases = 0;              // upper bound of the chunk's bases
   const uint64_t* items = nullptr;   // or an item list
@@ -376,7 +377,7 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
     size_t max_blocks;
     if ((rc = fastq_aux(h, src.rec_cap, src.max_bases, &aux, &max_blocks))) return rc;
     timing_begin(h, 0);
-    qh_launch_fastq_prepare(src.fastq, h->d_recs, (uint32_t)src.rec_cap, h->d_meta, g, aux, max_blocks, h->stream);
+    qh_launch_fastq_prepare(src.fastq, src.fastq_len, h->d_recs, (uint32_t)src.rec_cap, h->d_meta, g, aux, max_blocks, h->stream);
     timing_end(h, 0);
     timing_begin(h, 1);
     qh_launch_partition_fastq(aux, (uint32_t)src.rec_cap, h->d_meta, g, l1_dst, check_owner, h->stream);
@@ -421,6 +422,7 @@ extern "C" int qh_build_add_fastq_device(qh_build* h, const void* dev_buf, size_
   if (use_partition(h, len / 2)) {
     part_source src;
     src.fastq = (const uint8_t*)dev_buf;
+    src.fastq_len = len;
     src.rec_cap = rec_cap;
     src.max_bases = len / 2;
     if ((rc = run_partitioned(h, src, len / 2))) return rc;
@@ -460,7 +462,8 @@ extern "C" int qh_build_add_fastq(qh_build* h, const char* buf, size_t len) {
   return qh_build_add_fastq_device(h, h->d_chunk, len);
 }
 
-static int submit_records(qh_build* h, const uint8_t* dev_buf, const qh_record* recs, size_t nrec, size_t max_items) {
+static int submit_records(qh_build* h, const uint8_t* dev_buf, size_t buf_len, const qh_record* recs, size_t nrec,
+                          size_t max_items) {
   int rc = begin_chunk(h, max_items);
   if (rc) return rc;
   if ((rc = ensure((void**)&h->d_recs, &h->rec_cap, (nrec + 1) * 16, "record table"))) return rc;
@@ -472,6 +475,7 @@ static int submit_records(qh_build* h, const uint8_t* dev_buf, const qh_record* 
   if (use_partition(h, max_items)) {
     part_source src;
     src.fastq = dev_buf;
+    src.fastq_len = buf_len;
     src.rec_cap = nrec;
     src.max_bases = max_items;
     if ((rc = run_partitioned(h, src, max_items))) return rc;
@@ -498,7 +502,7 @@ extern "C" int qh_build_add_records_device(qh_build* h, const void* dev_buf, siz
       return qh_fail(QH_EBADARG, "record %zu lies outside the chunk", i);
     total += recs[i].len;
   }
-  return submit_records(h, (const uint8_t*)dev_buf, recs, nrec, total);
+  return submit_records(h, (const uint8_t*)dev_buf, len, recs, nrec, total);
 }
 
 // Sequential parser with jellyfish::whole_sequence_parser's FASTQ rules. Returns
@@ -601,7 +605,7 @@ extern "C" int qh_build_add_fastq_host_parsed(qh_build* h, const char* buf, size
     total += recs[i].len;
   }
   QH_HIP(hipStreamSynchronize(h->stream));
-  return submit_records(h, h->d_chunk, recs.data(), recs.size(), total);
+  return submit_records(h, h->d_chunk, extra_off + scratch.size() + 16, recs.data(), recs.size(), total);
 }
 
 // Contaminant set input: every canonical k-mer of a FASTA buffer, all with the
@@ -651,7 +655,7 @@ extern "C" int qh_build_add_fasta(qh_build* h, const char* buf, size_t len) {
   if ((rc = stage_chunk(h, seqs.data(), seqs.size(), quals.data(), quals.size(), &qoff))) return rc;
   for (size_t i = 0; i < recs.size(); ++i) recs[i].qual_off = (uint32_t)qoff;
   QH_HIP(hipStreamSynchronize(h->stream));
-  return submit_records(h, h->d_chunk, recs.data(), recs.size(), total);
+  return submit_records(h, h->d_chunk, qoff + quals.size() + 16, recs.data(), recs.size(), total);
 }
 
 // The contaminant database as error_correct_reads.cc:692-708 opens it, built from FASTA at the
@@ -748,7 +752,7 @@ extern "C" int qh_build_extract_partitioned_device(qh_build* h, const void* dev_
   qh_fastq_aux aux;
   size_t max_blocks;
   if ((rc = fastq_aux(h, rec_cap, len / 2, &aux, &max_blocks))) return rc;
-  qh_launch_fastq_prepare((const uint8_t*)dev_buf, h->d_recs, (uint32_t)rec_cap, h->d_meta, h->g, aux, max_blocks, h->stream);
+  qh_launch_fastq_prepare((const uint8_t*)dev_buf, len, h->d_recs, (uint32_t)rec_cap, h->d_meta, h->g, aux, max_blocks, h->stream);
   // bucket = owner shard = low shard_bits of the hash; a bucket that overflows is an error here
   qh_part_dst dst = {dev_out, cap_per_shard, (unsigned long long*)dev_counts, 0, h->g.shard_bits, 0, nullptr, 0};
   timing_begin(h, 1);

@@ -76,7 +76,7 @@ struct qh_fastq_aux {
   uint64_t* planes;
 };
 // record table -> prefixes, descriptors and the bit planes of the chunk (4 kernels)
-void qh_launch_fastq_prepare(const uint8_t* buf, const uint4* recs, uint32_t rec_cap, const qh_meta* meta,
+void qh_launch_fastq_prepare(const uint8_t* buf, size_t buf_len, const uint4* recs, uint32_t rec_cap, const qh_meta* meta,
                              const qh_geom& g, const qh_fastq_aux& a, uint64_t max_blocks, hipStream_t s);
 void qh_launch_partition_fastq(const qh_fastq_aux& a, uint32_t rec_cap, qh_meta* meta, const qh_geom& g,
                                const qh_part_dst& d, int check_owner, hipStream_t s);

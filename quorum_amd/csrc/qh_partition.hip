@@ -147,58 +147,112 @@ __global__ __launch_bounds__(256) void k_rec_blocks_apply(const uint4* __restric
   if (threadIdx.x == 0 && base + RB_TILE >= nrec) blk_prefix[nrec] = tile_sums[ntiles];
 }
 
-// FASTQ text -> bit planes, create_database.cc:73-84 for 64 bases at a time: a lane per base, the
-// wave's four ballots are the block's planes. Each wave takes QPK_BLOCKS consecutive blocks per
-// round with all their byte loads in flight together.
-#define QPK_BLOCKS 8
+// FASTQ text -> bit planes (create_database.cc:73-84), SWAR: a lane turns 8 consecutive bases
+// (two dwords of sequence, two of quality) into one byte of each of the block's four planes.
+// Per byte of text: valid = letter is A/C/G/T in either case (zero-byte tests on u ^ 'A'),
+// code = ((u >> 1) ^ (u >> 2)) & 3 (A 0, C 1, G 2, T 3), hq = quality >= threshold as signed
+// chars; the 8 x 4 flag bits are then transposed into 4 bytes by two delta swaps.
+__device__ __forceinline__ uint32_t swar_zero_bytes(uint32_t x) {  // 0x80 where a byte of x is 0
+  return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+}
 
-__global__ __launch_bounds__(256) void k_pack_planes(const uint8_t* __restrict__ buf, const uint4* __restrict__ blk_desc,
+// flags of 4 bases: bit 0 valid, 1 hq, 2 code bit 0, 3 code bit 1 of each byte
+__device__ __forceinline__ uint32_t swar_base_flags(uint32_t c, uint32_t q, uint32_t thr_low7, bool thr_neg) {
+  const uint32_t u = c & 0xDFDFDFDFu, e = u ^ 0x41414141u;
+  const uint32_t z = swar_zero_bytes(e & 0xFDFDFDFDu) | swar_zero_bytes(e ^ 0x06060606u) | swar_zero_bytes(e ^ 0x15151515u);
+  const uint32_t vm = (z - (z >> 7)) | z;  // 0xFF per valid byte
+  const uint32_t code2 = ((u << 1) ^ u) & 0x0C0C0C0Cu;
+  // signed q >= t  <=>  unsigned (q ^ 0x80) >= (t ^ 0x80); thr_low7 / thr_neg describe t ^ 0x80
+  const uint32_t a = q ^ 0x80808080u;
+  const uint32_t r = (a | 0x80808080u) - thr_low7;  // bit 7: low 7 bits of a >= low 7 bits of the threshold
+  const uint32_t ge = thr_neg ? (a & r) : (a | r);
+  return (code2 | ((ge >> 6) & 0x02020202u) | 0x01010101u) & vm;
+}
+
+#define QPK_UNROLL 2
+
+__global__ __launch_bounds__(256) void k_pack_planes(const uint8_t* __restrict__ buf, uint32_t buf_len,
+                                                     const uint4* __restrict__ blk_desc,
                                                      const uint32_t* __restrict__ blk_prefix,
-                                                     const qh_meta* __restrict__ meta, uint64_t* __restrict__ planes,
+                                                     const qh_meta* __restrict__ meta, uint8_t* __restrict__ planes,
                                                      int min_qual) {
   if (meta->format_err) return;
-  const uint32_t nblk = blk_prefix[meta->nrec];
-  const int lane = threadIdx.x & 63;
-  const uint32_t gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
-  for (uint64_t b0 = (uint64_t)gw * QPK_BLOCKS; b0 < nblk; b0 += (uint64_t)nw * QPK_BLOCKS) {
-    uint4 d = make_uint4(0, 0, 0, 0);
-    if (lane < QPK_BLOCKS && b0 + lane < nblk) d = blk_desc[b0 + lane];
-    uint8_t bb[QPK_BLOCKS];
-    int8_t qq[QPK_BLOCKS];
+  const uint64_t nunits = (uint64_t)blk_prefix[meta->nrec] * 8;  // 8 bases each
+  const uint32_t tb = ((uint32_t)(int8_t)min_qual ^ 0x80u) & 0xFFu;
+  const uint32_t thr_low7 = (tb & 0x7Fu) * 0x01010101u;
+  const bool thr_neg = (tb & 0x80u) != 0;
+  const uint32_t last_dw = (buf_len - 1) & ~3u;  // last dword that holds a byte of the chunk
+  const uint32_t* __restrict__ words = reinterpret_cast<const uint32_t*>(buf);
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  uint64_t u0 = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint4 dn[QPK_UNROLL];
 #pragma unroll
-    for (int sl = 0; sl < QPK_BLOCKS; ++sl) {
-      const uint32_t so = __builtin_amdgcn_readlane(d.x, sl), qo = __builtin_amdgcn_readlane(d.y, sl);
-      const uint32_t nv = __builtin_amdgcn_readlane(d.z, sl);
-      const uint32_t l = (uint32_t)lane < nv ? (uint32_t)lane : 0u;
-      bb[sl] = buf[(size_t)so + l];
-      qq[sl] = (int8_t)buf[(size_t)qo + l];
+  for (int r = 0; r < QPK_UNROLL; ++r) dn[r] = u0 + r * stride < nunits ? blk_desc[(u0 + r * stride) >> 3] : make_uint4(0, 0, 0, 0);
+  for (; u0 < nunits; u0 += QPK_UNROLL * stride) {
+    uint4 d[QPK_UNROLL];
+    uint32_t sw[QPK_UNROLL][3], qw[QPK_UNROLL][3];
+#pragma unroll
+    for (int r = 0; r < QPK_UNROLL; ++r) {
+      d[r] = dn[r];
+      const uint32_t off = (uint32_t)((u0 + r * stride) & 7) * 8;
+      const uint32_t sa = d[r].x + off, qa = d[r].y + off;
+      // three aligned dwords cover the 8 bytes at any alignment; dwords past the chunk are clamped
+      // (their bytes lie beyond the block's end and are masked below)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const uint32_t s_at = (sa & ~3u) + 4 * i, q_at = (qa & ~3u) + 4 * i;
+        sw[r][i] = words[(s_at < last_dw ? s_at : last_dw) >> 2];
+        qw[r][i] = words[(q_at < last_dw ? q_at : last_dw) >> 2];
+      }
+    }
+    // descriptors of the next round while these loads are in flight
+#pragma unroll
+    for (int r = 0; r < QPK_UNROLL; ++r) {
+      const uint64_t un = u0 + (QPK_UNROLL + r) * stride;
+      dn[r] = un < nunits ? blk_desc[un >> 3] : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
-    for (int sl = 0; sl < QPK_BLOCKS; ++sl) {
-      const uint32_t nv = __builtin_amdgcn_readlane(d.z, sl);
-      const int code = qh_code(bb[sl]);
-      const bool valid = code >= 0 && (uint32_t)lane < nv;
-      const uint64_t pv = __ballot(valid);
-      const uint64_t ph = __ballot(valid && (int)qq[sl] >= (int)(int8_t)min_qual);  // signed char compare (:81)
-      const uint64_t p0 = __ballot(valid && (code & 1));
-      const uint64_t p1 = __ballot(valid && (code & 2));
-      if (lane < 4 && b0 + sl < nblk) planes[(b0 + sl) * 4 + lane] = lane == 0 ? pv : lane == 1 ? ph : lane == 2 ? p0 : p1;
+    for (int r = 0; r < QPK_UNROLL; ++r) {
+      const uint64_t u = u0 + r * stride;
+      if (u >= nunits) break;
+      const uint32_t t8 = (uint32_t)(u & 7), off = t8 * 8;
+      const uint32_t sa = d[r].x + off, qa = d[r].y + off;
+      const uint32_t n = d[r].z > off ? (d[r].z - off < 8 ? d[r].z - off : 8) : 0;  // bases of the block in this unit
+      const uint32_t c_lo = __builtin_amdgcn_alignbyte(sw[r][1], sw[r][0], sa & 3u);
+      const uint32_t c_hi = __builtin_amdgcn_alignbyte(sw[r][2], sw[r][1], sa & 3u);
+      const uint32_t q_lo = __builtin_amdgcn_alignbyte(qw[r][1], qw[r][0], qa & 3u);
+      const uint32_t q_hi = __builtin_amdgcn_alignbyte(qw[r][2], qw[r][1], qa & 3u);
+      const uint64_t keep = n ? ~0ull >> (64 - 8 * n) : 0ull;
+      const uint32_t f_lo = swar_base_flags(c_lo, q_lo, thr_low7, thr_neg) & (uint32_t)keep;
+      const uint32_t f_hi = swar_base_flags(c_hi, q_hi, thr_low7, thr_neg) & (uint32_t)(keep >> 32);
+      // g: byte i = flags of base i (low nibble) and base i+4 (high nibble); transpose to
+      // byte p = plane p of the 8 bases
+      uint32_t g = f_lo | (f_hi << 4);
+      uint32_t t = ((g >> 7) ^ g) & 0x00AA00AAu;
+      g ^= t ^ (t << 7);
+      t = ((g >> 14) ^ g) & 0x0000CCCCu;
+      g ^= t ^ (t << 14);
+      uint8_t* o = planes + (u >> 3) * 32 + t8;
+      o[0] = (uint8_t)g;
+      o[8] = (uint8_t)(g >> 8);
+      o[16] = (uint8_t)(g >> 16);
+      o[24] = (uint8_t)(g >> 24);
     }
   }
 }
 
-void qh_launch_fastq_prepare(const uint8_t* buf, const uint4* recs, uint32_t rec_cap, const qh_meta* meta,
+void qh_launch_fastq_prepare(const uint8_t* buf, size_t buf_len, const uint4* recs, uint32_t rec_cap, const qh_meta* meta,
                              const qh_geom& g, const qh_fastq_aux& a, uint64_t max_blocks, hipStream_t s) {
   const uint32_t ntiles = (rec_cap + RB_TILE - 1) / RB_TILE;
   hipLaunchKernelGGL(k_rec_blocks_sum, dim3(ntiles), dim3(256), 0, s, recs, meta, a.tile_sums, ntiles, (uint32_t)g.k);
   hipLaunchKernelGGL(k_scan_u32, dim3(2), dim3(1024), 0, s, a.tile_sums, ntiles);
   hipLaunchKernelGGL(k_rec_blocks_apply, dim3(ntiles), dim3(256), 0, s, recs, meta, a.tile_sums, ntiles, (uint32_t)g.k,
                      a.blk_prefix, a.blk_desc, a.seg_desc);
-  uint64_t wgs = (max_blocks + 4 * QPK_BLOCKS - 1) / (4 * QPK_BLOCKS);
-  if (wgs > 256 * 8 * 4) wgs = 256 * 8 * 4;
+  uint64_t wgs = (max_blocks * 8 + 256 * QPK_UNROLL - 1) / (256 * QPK_UNROLL);
+  if (wgs > 256 * 8 * 2) wgs = 256 * 8 * 2;  // 8 workgroups of 256 threads fill a CU; two rounds of them
   if (wgs < 1) wgs = 1;
-  hipLaunchKernelGGL(k_pack_planes, dim3((unsigned)wgs), dim3(256), 0, s, buf, a.blk_desc, a.blk_prefix, meta, a.planes,
-                     g.min_qual);
+  hipLaunchKernelGGL(k_pack_planes, dim3((unsigned)wgs), dim3(256), 0, s, buf, (uint32_t)buf_len, a.blk_desc, a.blk_prefix,
+                     meta, reinterpret_cast<uint8_t*>(a.planes), g.min_qual);
 }
 
 // ------------------------------------------------------------- LDS-staged multi-split
