@@ -342,9 +342,9 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
   const qh_geom& g = h->g;
   const int wid_bits = g.lsize - QH_WINDOW_BITS;
   const uint32_t nw = 1u << wid_bits;
-  // measured on MI355X (profiles/): a 256-way last level after a coarse first level beats one
-  // 4096-way level (2.24 ms vs 2.45 ms for 152 M items); tables of up to 256 windows use one level
-  int b1 = wid_bits <= 8 ? wid_bits : wid_bits - 8;
+  // measured on MI355X (profiles/): two levels of about equal width beat one 4096-way level
+  // (1.29 ms vs 1.97 ms for 152 M items); tables of up to 256 windows use one level
+  int b1 = wid_bits <= 8 ? wid_bits : (wid_bits + 1) / 2;
   if (b1 > 12) b1 = 12;
   if (h->level1_bits >= 0 && h->level1_bits <= wid_bits && wid_bits - h->level1_bits <= 12) b1 = h->level1_bits;
   const int b2 = wid_bits - b1;
@@ -356,8 +356,8 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
   QH_HIP(hipMemsetAsync(h->d_bin_counts[1], 0, (size_t)nw * 8, h->stream));
   if (b2) {
     if ((rc = ensure((void**)&h->d_bins[0], &h->bins_cap[0], ((size_t)cap1 << b1) * 8, "level-1 buckets"))) return rc;
-    if ((rc = ensure((void**)&h->d_bin_counts[0], &h->bin_counts_cap[0], (size_t)8 << b1, "level-1 bucket counts"))) return rc;
-    QH_HIP(hipMemsetAsync(h->d_bin_counts[0], 0, (size_t)8 << b1, h->stream));
+    if ((rc = ensure((void**)&h->d_bin_counts[0], &h->bin_counts_cap[0], ((size_t)8 << b1) * QH_COUNT_STRIDE, "level-1 bucket counts"))) return rc;
+    QH_HIP(hipMemsetAsync(h->d_bin_counts[0], 0, ((size_t)8 << b1) * QH_COUNT_STRIDE, h->stream));
   }
   // spill list = the idle overflow buffer; failures of its direct insertion go to the active one
   const int cur = h->cur_ovf, other = cur ^ 1;
@@ -366,9 +366,9 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
   const uint64_t spill_cap = h->ovf_cap[other] / 8;
 
   qh_part_dst win_dst = {h->d_bins[1], capw, h->d_bin_counts[1], g.shard_bits + QH_WINDOW_BITS, b2 ? b2 : wid_bits,
-                         b2, spill, spill_cap};
+                         b2, spill, spill_cap, 1};
   qh_part_dst l1_dst = win_dst;
-  if (b2) l1_dst = {h->d_bins[0], cap1, h->d_bin_counts[0], g.shard_bits + QH_WINDOW_BITS + b2, b1, 0, spill, spill_cap};
+  if (b2) l1_dst = {h->d_bins[0], cap1, h->d_bin_counts[0], g.shard_bits + QH_WINDOW_BITS + b2, b1, 0, spill, spill_cap, QH_COUNT_STRIDE};
   else win_dst.out_bin_shift = 0;
   const int check_owner = g.shard_bits > 0;
 
@@ -383,13 +383,13 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
     qh_launch_partition_fastq(aux, (uint32_t)src.rec_cap, h->d_meta, g, l1_dst, check_owner, h->stream);
   } else {
     timing_begin(h, 1);
-    qh_launch_partition_items(src.items, src.n_items, nullptr, 1, src.n_items, src.hashed, h->d_meta, g, l1_dst,
+    qh_launch_partition_items(src.items, src.n_items, nullptr, 1, 1, src.n_items, src.hashed, h->d_meta, g, l1_dst,
                               check_owner, 1, h->stream);
   }
   timing_end(h, 1);
   if (b2) {
     timing_begin(h, 2);
-    qh_launch_partition_items(h->d_bins[0], cap1, h->d_bin_counts[0], 1u << b1, 0, 1, h->d_meta, g, win_dst, 0, 0, h->stream);
+    qh_launch_partition_items(h->d_bins[0], cap1, h->d_bin_counts[0], QH_COUNT_STRIDE, 1u << b1, 0, 1, h->d_meta, g, win_dst, 0, 0, h->stream);
     timing_end(h, 2);
   }
   timing_begin(h, 3);
@@ -754,7 +754,7 @@ extern "C" int qh_build_extract_partitioned_device(qh_build* h, const void* dev_
   if ((rc = fastq_aux(h, rec_cap, len / 2, &aux, &max_blocks))) return rc;
   qh_launch_fastq_prepare((const uint8_t*)dev_buf, len, h->d_recs, (uint32_t)rec_cap, h->d_meta, h->g, aux, max_blocks, h->stream);
   // bucket = owner shard = low shard_bits of the hash; a bucket that overflows is an error here
-  qh_part_dst dst = {dev_out, cap_per_shard, (unsigned long long*)dev_counts, 0, h->g.shard_bits, 0, nullptr, 0};
+  qh_part_dst dst = {dev_out, cap_per_shard, (unsigned long long*)dev_counts, 0, h->g.shard_bits, 0, nullptr, 0, 1};
   timing_begin(h, 1);
   qh_launch_partition_fastq(aux, (uint32_t)rec_cap, h->d_meta, h->g, dst, 0, h->stream);
   timing_end(h, 1);

@@ -104,12 +104,19 @@ __device__ __forceinline__ uint32_t window_top32(uint64_t cur, uint64_t prev, in
 // m < rm as 2-bit packed integers is decided at the most significant base where they differ:
 // with that base shifted to bit 31, forward wins iff its high bit is 0 where the high bits
 // differ, else iff its low bit is 0.
-__device__ __forceinline__ uint64_t qh_canonical_pkey(uint32_t m0, uint32_t m1, uint32_t r0, uint32_t r1, int k) {
+__device__ __forceinline__ void qh_canonical_planes(uint32_t m0, uint32_t m1, uint32_t r0, uint32_t r1, uint32_t* c0,
+                                                    uint32_t* c1) {
   const uint32_t d1 = m1 ^ r1, d = (m0 ^ r0) | d1;
   const int c = __clz((int)d) & 31;  // d == 0 (palindrome): either
   const uint32_t sel = ((int32_t)(d1 << c) < 0) ? m1 : m0;
   const bool fwd = (int32_t)(sel << c) >= 0;
-  const uint32_t c0 = fwd ? m0 : r0, c1 = fwd ? m1 : r1;
+  *c0 = fwd ? m0 : r0;
+  *c1 = fwd ? m1 : r1;
+}
+
+__device__ __forceinline__ uint64_t qh_canonical_pkey(uint32_t m0, uint32_t m1, uint32_t r0, uint32_t r1, int k) {
+  uint32_t c0, c1;
+  qh_canonical_planes(m0, m1, r0, r1, &c0, &c1);
   return (uint64_t)c0 | ((uint64_t)c1 << k);
 }
 

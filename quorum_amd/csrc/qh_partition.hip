@@ -262,6 +262,7 @@ struct qp_params {
   uint64_t* out;
   uint64_t out_cap;
   unsigned long long* out_counts;
+  uint32_t out_count_stride;  // counters of consecutive buckets lie this many words apart (contention, see qh_kernels.h)
   int bin_shift;       // bin = (h >> bin_shift) & bin_mask
   uint32_t bin_mask;
   int out_bin_shift;   // ob = (input bucket << out_bin_shift) | bin
@@ -278,6 +279,7 @@ struct qp_params {
   const uint64_t* in;
   uint64_t in_cap;
   const unsigned long long* in_counts;
+  uint32_t in_count_stride;
   uint64_t in_n;
   int in_hashed;       // 0: (mer<<1|q) as the C ABI passes them, 1: (hash<<1|q)
   int ablate;          // timing experiments only (QH_ABLATE): 16 no write-out, 32 no placement, 64 no histogram
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
     ntiles = ((uint64_t)nseg + QP_THREADS - 1) / QP_THREADS;
   } else {
     src = p.in + (uint64_t)blockIdx.y * p.in_cap;
-    src_n = p.in_counts ? (uint64_t)p.in_counts[blockIdx.y] : p.in_n;
+    src_n = p.in_counts ? (uint64_t)p.in_counts[(size_t)blockIdx.y * p.in_count_stride] : p.in_n;
     if (src_n > p.in_cap) src_n = p.in_cap;
     ntiles = (src_n + QP_TILE_ITEMS - 1) / QP_TILE_ITEMS;
   }
@@ -384,7 +386,9 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
             const uint32_t q = ((uint32_t)(wh >> j) & kones) == kones;         // high_len >= k (:86)
             const uint32_t r0 = ~(uint32_t)(w0 >> j) & kones, r1 = ~(uint32_t)(w1 >> j) & kones;
             const uint32_t m0 = (uint32_t)(f0 >> (QP_SEG - 1 - j)) & kones, m1 = (uint32_t)(f1 >> (QP_SEG - 1 - j)) & kones;
-            const uint64_t h = qh_mix(qh_canonical_pkey(m0, m1, r0, r1, g.k), g.k);
+            uint32_t c0, c1;
+            qh_canonical_planes(m0, m1, r0, r1, &c0, &c1);
+            const uint64_t h = qh_mix2(c0, c1, g.k);
             if (p.check_owner && ((uint32_t)h & smask) != (uint32_t)g.shard_id) {
               ++n_foreign;
             } else {
@@ -452,9 +456,10 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
           offs[b] = run;
           cursor[b] = run;
           // reserve the bucket range now, look at the answer only after the placement pass
-          resv[e] = c[e] ? (uint32_t)atomicAdd(&p.out_counts[((uint64_t)in_bucket << p.out_bin_shift) | b],
-                                               (unsigned long long)c[e])
-                         : 0u;
+          resv[e] = c[e] && !(p.ablate & 128)
+                        ? (uint32_t)atomicAdd(&p.out_counts[(((uint64_t)in_bucket << p.out_bin_shift) | b) * p.out_count_stride],
+                                              (unsigned long long)c[e])
+                        : 0u;
           run += c[e];
         }
       }
@@ -498,6 +503,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
 
 static void fill_common(qp_params& p, const qh_part_dst& d, qh_meta* meta, int check_owner, int count_instances) {
   p.out = d.out; p.out_cap = d.out_cap; p.out_counts = d.out_counts;
+  p.out_count_stride = d.out_count_stride ? d.out_count_stride : 1;
   p.bin_shift = d.bin_shift; p.bin_mask = (1u << d.bin_bits) - 1; p.out_bin_shift = d.out_bin_shift;
   p.spill = d.spill; p.spill_cap = d.spill_cap; p.meta = meta;
   p.check_owner = check_owner; p.count_instances = count_instances;
@@ -515,11 +521,11 @@ void qh_launch_partition_fastq(const qh_fastq_aux& a, uint32_t rec_cap, qh_meta*
 }
 
 void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsigned long long* in_counts,
-                               uint32_t n_in_buckets, uint64_t in_n, int in_hashed, qh_meta* meta, const qh_geom& g,
+                               uint32_t in_count_stride, uint32_t n_in_buckets, uint64_t in_n, int in_hashed, qh_meta* meta, const qh_geom& g,
                                const qh_part_dst& d, int check_owner, int count_instances, hipStream_t s) {
   qp_params p = {};
   fill_common(p, d, meta, check_owner, count_instances);
-  p.in = in; p.in_cap = in_cap; p.in_counts = in_counts; p.in_n = in_n; p.in_hashed = in_hashed;
+  p.in = in; p.in_cap = in_cap; p.in_counts = in_counts; p.in_count_stride = in_count_stride ? in_count_stride : 1; p.in_n = in_n; p.in_hashed = in_hashed;
   const uint64_t most = in_counts ? in_cap : in_n;
   uint64_t tiles = (most + QP_TILE_ITEMS - 1) / QP_TILE_ITEMS;
   if (tiles < 1) tiles = 1;

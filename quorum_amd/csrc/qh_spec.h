@@ -38,10 +38,9 @@
 #endif
 
 #define QH_WINDOW_BITS 14          // 16384 slots = 128 KiB: one window fits a CU's LDS
-#define QH_MIX_C1 0xff51afd7ed558ccdULL
-#define QH_MIX_C2 0xc4ceb9fe1a85ec53ULL
-#define QH_MIX_C1_INV 0x4f74430c22a54005ULL   // C1 * C1_INV == 1 (mod 2^64)
-#define QH_MIX_C2_INV 0x9cb4b2f8129337dbULL   // C2 * C2_INV == 1 (mod 2^64)
+#define QH_MIX_C1 0x9E3779B1u
+#define QH_MIX_C2 0x85EBCA77u
+#define QH_MIX_C3 0xC2B2AE3Du
 
 struct qh_geom {
   int32_t k;            // mer length, 1..31
@@ -63,28 +62,34 @@ struct qh_geom {
 
 QH_HD uint64_t qh_low_mask(int n) { return n >= 64 ? ~0ULL : ((1ULL << n) - 1); }
 
-// xorshift / odd-multiply rounds on n = 2k bits; every step is a bijection of
-// [0, 2^n), so the stored remainder + home position determine the key.
+// Position hash: a 3-round Feistel network on the two k-bit halves of the plane key
+// (L = low code bits, R = high code bits), round function = top k bits of a 32-bit odd
+// multiply. Any Feistel network is a bijection of [0, 2^2k), so the stored remainder + home
+// position determine the key. The half updated twice (R) becomes the LOW half of the hash: it
+// carries the shard / window / slot bits. 32-bit arithmetic only: the wide multiplies of a
+// 64-bit mixer are quarter rate on CDNA and were ~45 % of the extraction kernel's VALU time.
+// (k <= 31 is enforced at qh_make_geom.)
+QH_HD uint64_t qh_mix2(uint32_t L, uint32_t R, int k) {
+  const int sh = 32 - k;
+  R ^= (L * QH_MIX_C1) >> sh;
+  L ^= (R * QH_MIX_C2) >> sh;
+  R ^= (L * QH_MIX_C3) >> sh;
+  return (uint64_t)R | ((uint64_t)L << k);
+}
+
 QH_HD uint64_t qh_mix(uint64_t x, int k) {
-  const int n = 2 * k, s = (n + 1) >> 1;
-  const uint64_t m = qh_low_mask(n);
-  x ^= x >> s;
-  x = (x * QH_MIX_C1) & m;
-  x ^= x >> s;
-  x = (x * QH_MIX_C2) & m;
-  x ^= x >> s;
-  return x;
+  const uint32_t km = (uint32_t)((1ull << k) - 1);
+  return qh_mix2((uint32_t)x & km, (uint32_t)(x >> k) & km, k);
 }
 
 QH_HD uint64_t qh_unmix(uint64_t x, int k) {
-  const int n = 2 * k, s = (n + 1) >> 1;
-  const uint64_t m = qh_low_mask(n);
-  x ^= x >> s;                       // 2s >= n: the xorshift is an involution
-  x = (x * QH_MIX_C2_INV) & m;
-  x ^= x >> s;
-  x = (x * QH_MIX_C1_INV) & m;
-  x ^= x >> s;
-  return x;
+  const uint32_t km = (uint32_t)((1ull << k) - 1);
+  const int sh = 32 - k;
+  uint32_t R = (uint32_t)x & km, L = (uint32_t)(x >> k) & km;
+  R ^= (L * QH_MIX_C3) >> sh;
+  L ^= (R * QH_MIX_C2) >> sh;
+  R ^= (L * QH_MIX_C1) >> sh;
+  return (uint64_t)L | ((uint64_t)R << k);
 }
 
 // reverse complement of a k-mer in the low 2k bits (A=0,C=1,G=2,T=3: comp = 3-c = ~c)

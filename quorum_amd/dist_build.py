@@ -13,8 +13,9 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-MIX_C1 = np.uint64(0xff51afd7ed558ccd)
-MIX_C2 = np.uint64(0xc4ceb9fe1a85ec53)
+MIX_C1 = np.uint64(0x9E3779B1)
+MIX_C2 = np.uint64(0x85EBCA77)
+MIX_C3 = np.uint64(0xC2B2AE3D)
 
 
 def _compress_even(x):
@@ -46,32 +47,25 @@ def key_from_pkey_np(pk, k):
 
 
 def mix_np(x, k):
-    """qh_mix (quorum_amd/csrc/qh_spec.h) on a uint64 array of plane keys"""
-    x = np.asarray(x, dtype=np.uint64).copy()
-    n = 2 * k
-    s = np.uint64((n + 1) >> 1)
-    m = np.uint64((1 << n) - 1)
-    with np.errstate(over="ignore"):
-        x ^= x >> s
-        x = (x * MIX_C1) & m
-        x ^= x >> s
-        x = (x * MIX_C2) & m
-        x ^= x >> s
-    return x
+    """qh_mix (quorum_amd/csrc/qh_spec.h) on a uint64 array of plane keys: 3-round Feistel on the
+    two k-bit halves, the twice-updated half ending up low"""
+    x = np.asarray(x, dtype=np.uint64)
+    km, kk, sh, m32 = np.uint64((1 << k) - 1), np.uint64(k), np.uint64(32 - k), np.uint64(0xFFFFFFFF)
+    L, R = x & km, (x >> kk) & km
+    R = R ^ (((L * MIX_C1) & m32) >> sh)
+    L = L ^ (((R * MIX_C2) & m32) >> sh)
+    R = R ^ (((L * MIX_C3) & m32) >> sh)
+    return R | (L << kk)
 
 
 def unmix_np(x, k):
-    x = np.asarray(x, dtype=np.uint64).copy()
-    n = 2 * k
-    s = np.uint64((n + 1) >> 1)
-    m = np.uint64((1 << n) - 1)
-    with np.errstate(over="ignore"):
-        x ^= x >> s
-        x = (x * np.uint64(0x9cb4b2f8129337db)) & m
-        x ^= x >> s
-        x = (x * np.uint64(0x4f74430c22a54005)) & m
-        x ^= x >> s
-    return x
+    x = np.asarray(x, dtype=np.uint64)
+    km, kk, sh, m32 = np.uint64((1 << k) - 1), np.uint64(k), np.uint64(32 - k), np.uint64(0xFFFFFFFF)
+    R, L = x & km, (x >> kk) & km
+    R = R ^ (((L * MIX_C3) & m32) >> sh)
+    L = L ^ (((R * MIX_C2) & m32) >> sh)
+    R = R ^ (((L * MIX_C1) & m32) >> sh)
+    return L | (R << kk)
 
 
 def hash_np(mers, k):
