@@ -43,6 +43,26 @@ def test_partitioned_matches_oracle(size, level1_bits, chunks, k, bits):
     assert (m2 == om).all() and (v2 == ov).all()
 
 
+@pytest.mark.parametrize("k,bits,size", [(12, 2, 1 << 18), (16, 7, 1 << 20), (24, 3, 1 << 26)])
+def test_window_kernels_agree(k, bits, size, monkeypatch):
+    """the counting form of the window build ([tag | H | L] words, one add per sighting) against the
+    compare-and-swap form and the oracle: deep coverage (saturating counts), mixed qualities, three
+    chunks so that windows are converted from and to the table's form with content in them"""
+    rng = np.random.default_rng(k * 100 + bits)
+    data = random_fastq(rng, 9000, k=k, genome=rng.integers(0, 4, size=3000))
+    db = po.OracleDB(1 << 20, k, bits)
+    n = db.add_fastq(data, 38, threads=4)
+    om, ov = db.sorted_dump()
+    assert (ov >> np.uint64(1)).max() == (1 << bits) - 1  # saturation is reached
+    assert 0 < (ov & np.uint64(1)).sum() < ov.size        # both quality levels present
+    for kernel in ("count", "cas"):
+        monkeypatch.setenv("QH_WINDOW_KERNEL", kernel)
+        h, st, m, v = build(data, k, bits, size, "partition", chunks=3)
+        assert st["instances"] == n and st["distinct"] == om.size
+        assert (m == om).all() and (v == ov).all(), kernel
+        h.close()
+
+
 def test_partitioned_growth_and_contention():
     """a 16384-slot table receiving far more distinct k-mers than it holds: windows overflow, the
     spill list is inserted directly, the table doubles; plus a poly-A read (one slot, 5000 updates)"""
