@@ -138,7 +138,7 @@ extern "C" void qh_build_destroy(qh_build* h) {
   if (!h) return;
   hipError_t e = hipSetDevice(h->device); (void)e;
   if (h->stream) { e = hipStreamSynchronize(h->stream); (void)e; }
-  void* ptrs[] = {h->table, h->d_meta, h->d_chunk, h->d_recs, h->d_tiles, h->d_ovf[0], h->d_ovf[1], h->d_items, h->d_shard_counts, h->d_blkprefix, h->d_rbsums, h->d_blkdesc, h->d_segdesc, h->d_planes,
+  void* ptrs[] = {h->table, h->d_meta, h->d_chunk, h->d_recs, h->d_tiles, h->d_ovf[0], h->d_ovf[1], h->d_items, h->d_shard_counts, h->d_rbsums, h->d_segdesc, h->d_planes,
                   h->d_bins[0], h->d_bins[1], h->d_bin_counts[0], h->d_bin_counts[1]};
   for (void* p : ptrs) if (p) { e = hipFree(p); (void)e; }
   if (h->h_meta) { e = hipHostFree(h->h_meta); (void)e; }
@@ -314,17 +314,14 @@ static bool use_partition(const qh_build* h, size_t max_items) {
   return wid_bits >= 8 && max_items >= (((size_t)1 << h->g.lsize) >> 3);
 }
 
-// device arrays of the FASTQ source for a chunk of at most rec_cap records / max_bases bases
-static int fastq_aux(qh_build* h, size_t rec_cap, size_t max_bases, qh_fastq_aux* a, size_t* max_blocks) {
-  const size_t blocks = max_bases / 64 + rec_cap, segs = max_bases / QH_SEG_KMERS + rec_cap;
+// device arrays of the FASTQ source for a chunk of buf_len bytes, at most rec_cap records / max_bases bases
+static int fastq_aux(qh_build* h, size_t buf_len, size_t rec_cap, size_t max_bases, qh_fastq_aux* a) {
+  const size_t segs = max_bases / QH_SEG_KMERS + rec_cap, plane_words = (buf_len + 63) / 64 + 2;
   int rc;
-  if ((rc = ensure((void**)&h->d_rbsums, &h->rbsums_cap, (2 * (rec_cap / 1024 + 2) + 2) * 4, "record block sums"))) return rc;
-  if ((rc = ensure((void**)&h->d_blkprefix, &h->blkprefix_cap, (rec_cap + 2) * 4, "record block prefix"))) return rc;
-  if ((rc = ensure((void**)&h->d_blkdesc, &h->blkdesc_cap, (blocks + 2) * 16, "block descriptors"))) return rc;
-  if ((rc = ensure((void**)&h->d_segdesc, &h->segdesc_cap, (segs + 2) * 8, "segment descriptors"))) return rc;
-  if ((rc = ensure((void**)&h->d_planes, &h->planes_cap, (blocks + 2) * 32, "bit planes"))) return rc;
-  *a = {h->d_rbsums, h->d_blkprefix, h->d_blkdesc, h->d_segdesc, h->d_planes};
-  *max_blocks = blocks;
+  if ((rc = ensure((void**)&h->d_rbsums, &h->rbsums_cap, (rec_cap / 1024 + 4) * 4, "segment sums"))) return rc;
+  if ((rc = ensure((void**)&h->d_segdesc, &h->segdesc_cap, (segs + 2) * 16, "segment descriptors"))) return rc;
+  if ((rc = ensure((void**)&h->d_planes, &h->planes_cap, plane_words * 32, "bit planes"))) return rc;
+  *a = {h->d_rbsums, h->d_segdesc, h->d_planes, plane_words};
   return QH_OK;
 }
 
@@ -374,10 +371,10 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
 
   if (src.fastq) {
     qh_fastq_aux aux;
-    size_t max_blocks;
-    if ((rc = fastq_aux(h, src.rec_cap, src.max_bases, &aux, &max_blocks))) return rc;
+    if ((rc = fastq_aux(h, src.fastq_len, src.rec_cap, src.max_bases, &aux))) return rc;
     timing_begin(h, 0);
-    qh_launch_fastq_prepare(src.fastq, src.fastq_len, h->d_recs, (uint32_t)src.rec_cap, h->d_meta, g, aux, max_blocks, h->stream);
+    qh_launch_text_planes(src.fastq, src.fastq_len, g, aux, h->stream);
+    qh_launch_segments(h->d_recs, (uint32_t)src.rec_cap, h->d_meta, g, aux, h->stream);
     timing_end(h, 0);
     timing_begin(h, 1);
     qh_launch_partition_fastq(aux, (uint32_t)src.rec_cap, h->d_meta, g, l1_dst, check_owner, h->stream);
@@ -750,9 +747,9 @@ extern "C" int qh_build_extract_partitioned_device(qh_build* h, const void* dev_
   if ((rc = ensure((void**)&h->d_recs, &h->rec_cap, rec_cap * 16, "record table"))) return rc;
   qh_launch_index_fastq((const uint8_t*)dev_buf, len, h->d_tiles, h->d_recs, (uint32_t)rec_cap, h->d_meta, h->stream);
   qh_fastq_aux aux;
-  size_t max_blocks;
-  if ((rc = fastq_aux(h, rec_cap, len / 2, &aux, &max_blocks))) return rc;
-  qh_launch_fastq_prepare((const uint8_t*)dev_buf, len, h->d_recs, (uint32_t)rec_cap, h->d_meta, h->g, aux, max_blocks, h->stream);
+  if ((rc = fastq_aux(h, len, rec_cap, len / 2, &aux))) return rc;
+  qh_launch_text_planes((const uint8_t*)dev_buf, len, h->g, aux, h->stream);
+  qh_launch_segments(h->d_recs, (uint32_t)rec_cap, h->d_meta, h->g, aux, h->stream);
   // bucket = owner shard = low shard_bits of the hash; a bucket that overflows is an error here
   qh_part_dst dst = {dev_out, cap_per_shard, (unsigned long long*)dev_counts, 0, h->g.shard_bits, 0, nullptr, 0, 1};
   timing_begin(h, 1);

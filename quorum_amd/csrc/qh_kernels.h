@@ -66,24 +66,23 @@ struct qh_part_dst {
   uint32_t out_count_stride;
 };
 #define QH_COUNT_STRIDE 513u
-// Per-chunk device arrays of the FASTQ source (sizes for rec_cap records, max_blocks 64-base
-// blocks, max_segs segments of QH_SEG_KMERS k-mers):
-//   tile_sums  2 * (ceil(rec_cap/1024) + 1) words   scan scratch; holds the block / segment totals
-//   blk_prefix rec_cap + 1 words                     exclusive prefix of blocks per record
-//   blk_desc   max_blocks x 16 B                     {seq offset, qual offset, bases, index in read}
-//   seg_desc   max_segs x 8 B                        {plane block, bit offset | k-mers << 8}
-//   planes     (max_blocks + 2) x 32 B               valid / high-quality / code bit 0 / code bit 1
+// Per-chunk device arrays of the FASTQ source (qh_partition.hip):
+//   tile_sums  ceil(rec_cap/1024) + 1 words     scan scratch; ends with the segment total
+//   seg_desc   max_segs x 16 B                   {first base offset, its quality offset, k-mers, 0}
+//   planes     4 planes x plane_words words      v, h, l0, l1: one bit per byte of the chunk;
+//                                                plane_words >= ceil(len / 64) + 2
 #define QH_SEG_KMERS 12
 struct qh_fastq_aux {
   uint32_t* tile_sums;
-  uint32_t* blk_prefix;
-  uint4* blk_desc;
-  uint2* seg_desc;
+  uint4* seg_desc;
   uint64_t* planes;
+  uint64_t plane_words;
 };
-// record table -> prefixes, descriptors and the bit planes of the chunk (4 kernels)
-void qh_launch_fastq_prepare(const uint8_t* buf, size_t buf_len, const uint4* recs, uint32_t rec_cap, const qh_meta* meta,
-                             const qh_geom& g, const qh_fastq_aux& a, uint64_t max_blocks, hipStream_t s);
+// chunk text -> bit planes (one streaming pass, no record knowledge)
+void qh_launch_text_planes(const uint8_t* buf, size_t len, const qh_geom& g, const qh_fastq_aux& a, hipStream_t s);
+// record table -> segment descriptors (3 small kernels)
+void qh_launch_segments(const uint4* recs, uint32_t rec_cap, const qh_meta* meta, const qh_geom& g,
+                        const qh_fastq_aux& a, hipStream_t s);
 void qh_launch_partition_fastq(const qh_fastq_aux& a, uint32_t rec_cap, qh_meta* meta, const qh_geom& g,
                                const qh_part_dst& d, int check_owner, hipStream_t s);
 void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsigned long long* in_counts,

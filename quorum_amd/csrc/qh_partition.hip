@@ -29,47 +29,42 @@
 #define QP_MAX_BINS 4096
 #define QP_NONE (~0ull)
 
-// ------------------------- per-record prefixes, descriptors and bit planes of a FASTQ chunk
+// ------------------------------- bit planes and segment descriptors of a FASTQ chunk
 //
-// A record of `len` bases owns ceil(len/64) plane BLOCKS (32 bytes each: the valid, high-quality,
-// code-bit-0 and code-bit-1 planes of 64 consecutive positions) and ceil((len-k+1)/QP_SEG)
-// SEGMENTS of up to QP_SEG consecutive k-mers, the unit of work of one extraction lane.
+// TEXT PLANES: four bit arrays with one bit per BYTE of the chunk, whatever the byte is part of:
+//   v  the byte is A/C/G/T in either case      l0, l1  its 2-bit code (A 0, C 1, G 2, T 3)
+//   h  the byte, read as a signed char quality, is >= the threshold (create_database.cc:81)
+// stored as 64-bit words (word j = bytes 64j .. 64j+63), plane after plane. A read's bases are
+// the v/l0/l1 bits at its sequence offset and the h bits at its quality offset, so the planes are
+// made by one streaming pass that knows nothing about records.
+//
+// SEGMENTS: up to QP_SEG consecutive k-mers of one read, the unit of work of one extraction lane:
+// {byte offset of the first base, byte offset of its quality, k-mers, 0}.
 
 #define RB_TILE 1024  // records per scan tile
 #define QP_SEG 12     // k-mers per segment (= items a lane keeps in registers per tile)
 
-__device__ __forceinline__ uint32_t rec_nblocks(uint32_t len) { return (len + 63) >> 6; }
 __device__ __forceinline__ uint32_t rec_nsegs(uint32_t len, uint32_t k) {
   return len >= k ? (len - k + 1 + QP_SEG - 1) / QP_SEG : 0;
 }
 
-// tile_sums: [0, ntiles] block sums (total at [ntiles]), [ntiles+1, 2*ntiles+1] segment sums
-__global__ __launch_bounds__(256) void k_rec_blocks_sum(const uint4* __restrict__ recs, const qh_meta* __restrict__ meta,
-                                                        uint32_t* __restrict__ tile_sums, uint32_t ntiles, uint32_t k) {
-  __shared__ uint32_t ws[2][4];
+// tile_sums: [0, ntiles) segments per tile of RB_TILE records; the scan leaves the total at [ntiles]
+__global__ __launch_bounds__(256) void k_rec_segs_sum(const uint4* __restrict__ recs, const qh_meta* __restrict__ meta,
+                                                      uint32_t* __restrict__ tile_sums, uint32_t k) {
+  __shared__ uint32_t ws[4];
   const uint32_t nrec = meta->format_err ? 0 : meta->nrec;
   const uint32_t base = blockIdx.x * RB_TILE;
-  uint32_t s = 0, t = 0;
-  for (uint32_t r = base + threadIdx.x; r < base + RB_TILE && r < nrec; r += 256) {
-    const uint32_t len = recs[r].y;
-    s += rec_nblocks(len);
-    t += rec_nsegs(len, k);
-  }
-  s = wave_sum_u32(s);
+  uint32_t t = 0;
+  for (uint32_t r = base + threadIdx.x; r < base + RB_TILE && r < nrec; r += 256) t += rec_nsegs(recs[r].y, k);
   t = wave_sum_u32(t);
-  if ((threadIdx.x & 63) == 0) { ws[0][threadIdx.x >> 6] = s; ws[1][threadIdx.x >> 6] = t; }
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = t;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    tile_sums[blockIdx.x] = ws[0][0] + ws[0][1] + ws[0][2] + ws[0][3];
-    tile_sums[ntiles + 1 + blockIdx.x] = ws[1][0] + ws[1][1] + ws[1][2] + ws[1][3];
-  }
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-// exclusive scan of n u32 values in place by one workgroup; the total goes to v[n]. Workgroup b
-// scans the array that starts at v + b * (n + 1).
-__global__ __launch_bounds__(1024) void k_scan_u32(uint32_t* __restrict__ v0, uint32_t n) {
+// exclusive scan of n u32 values in place by one workgroup; the total goes to v[n]
+__global__ __launch_bounds__(1024) void k_scan_u32(uint32_t* __restrict__ v, uint32_t n) {
   __shared__ uint32_t part[1024];
-  uint32_t* v = v0 + (size_t)blockIdx.x * (n + 1);
   const uint32_t per = (n + 1023) / 1024;
   const uint32_t b = threadIdx.x * per;
   uint32_t s = 0;
@@ -91,169 +86,113 @@ __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t* __restrict__ v0, ui
   if (threadIdx.x == 1023) v[n] = part[1023];
 }
 
-__global__ __launch_bounds__(256) void k_rec_blocks_apply(const uint4* __restrict__ recs, const qh_meta* __restrict__ meta,
-                                                          const uint32_t* __restrict__ tile_sums, uint32_t ntiles,
-                                                          uint32_t k, uint32_t* __restrict__ blk_prefix,
-                                                          uint4* __restrict__ blk_desc, uint2* __restrict__ seg_desc) {
-  __shared__ uint32_t wtot[2][4];
+__global__ __launch_bounds__(256) void k_rec_segs_apply(const uint4* __restrict__ recs, const qh_meta* __restrict__ meta,
+                                                        const uint32_t* __restrict__ tile_sums, uint32_t k,
+                                                        uint4* __restrict__ seg_desc) {
+  __shared__ uint32_t wtot[4];
   const uint32_t nrec = meta->format_err ? 0 : meta->nrec;
   const uint32_t base = blockIdx.x * RB_TILE;
-  if (base >= nrec) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) blk_prefix[0] = 0;  // nrec == 0
-    return;
-  }
-  uint32_t run = tile_sums[blockIdx.x], srun = tile_sums[ntiles + 1 + blockIdx.x];
+  if (base >= nrec) return;
+  uint32_t srun = tile_sums[blockIdx.x];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (uint32_t j = 0; j < RB_TILE; j += 256) {
     const uint32_t r = base + j + threadIdx.x;
     const uint4 rc = r < nrec ? recs[r] : make_uint4(0, 0, 0, 0);
-    const uint32_t c = rec_nblocks(rc.y), cs = rec_nsegs(rc.y, k);
-    uint32_t inc = c, sinc = cs;
+    const uint32_t cs = rec_nsegs(rc.y, k);
+    uint32_t sinc = cs;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t x = __shfl_up(inc, o, 64), y = __shfl_up(sinc, o, 64);
-      if (lane >= o) { inc += x; sinc += y; }
+      const uint32_t y = __shfl_up(sinc, o, 64);
+      if (lane >= o) sinc += y;
     }
-    if (lane == 63) { wtot[0][wv] = inc; wtot[1][wv] = sinc; }
+    if (lane == 63) wtot[wv] = sinc;
     __syncthreads();
-    uint32_t wbase = 0, tot = 0, swbase = 0, stot = 0;
+    uint32_t swbase = 0, stot = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      const uint32_t x = wtot[0][w], y = wtot[1][w];
-      if (w < wv) { wbase += x; swbase += y; }
-      tot += x; stot += y;
+      const uint32_t y = wtot[w];
+      if (w < wv) swbase += y;
+      stot += y;
     }
-    if (r < nrec) {
-      const uint32_t pb = run + wbase + inc - c;
-      blk_prefix[r] = pb;
-      // descriptor of every 64-base block: {sequence offset, quality offset, bases in the block,
-      // index of the block inside its read}
-      for (uint32_t b = 0; b < c; ++b) {
-        const uint32_t left = rc.y - b * 64;
-        blk_desc[pb + b] = make_uint4(rc.x + b * 64, rc.z + b * 64, left < 64 ? left : 64, b);
-      }
-      // descriptor of every segment: k-mers [a, a + n) of the read (k-mer i spans positions
-      // i .. i+k-1) = {plane block of position a, (a & 63) | n << 8}
-      const uint32_t ps = srun + swbase + sinc - cs;
-      const uint32_t nk = cs ? rc.y - k + 1 : 0;
+    if (cs) {
+      // k-mers [a, a + n) of the read; k-mer i spans bases i .. i+k-1
+      const uint32_t ps = srun + swbase + sinc - cs, nk = rc.y - k + 1;
       for (uint32_t b = 0; b < cs; ++b) {
         const uint32_t a = b * QP_SEG, left = nk - a;
-        seg_desc[ps + b] = make_uint2(pb + (a >> 6), (a & 63) | ((left < QP_SEG ? left : QP_SEG) << 8));
+        seg_desc[ps + b] = make_uint4(rc.x + a, rc.z + a, left < QP_SEG ? left : QP_SEG, 0);
       }
     }
-    run += tot;
     srun += stot;
     __syncthreads();
   }
-  if (threadIdx.x == 0 && base + RB_TILE >= nrec) blk_prefix[nrec] = tile_sums[ntiles];
 }
 
-// FASTQ text -> bit planes (create_database.cc:73-84), SWAR: a lane turns 8 consecutive bases
-// (two dwords of sequence, two of quality) into one byte of each of the block's four planes.
-// Per byte of text: valid = letter is A/C/G/T in either case (zero-byte tests on u ^ 'A'),
-// code = ((u >> 1) ^ (u >> 2)) & 3 (A 0, C 1, G 2, T 3), hq = quality >= threshold as signed
-// chars; the 8 x 4 flag bits are then transposed into 4 bytes by two delta swaps.
+// SWAR over 4 bytes of text at a time: zero-byte tests on u ^ 'A' give validity, two shifts the
+// code, a biased subtract the signed quality compare.
 __device__ __forceinline__ uint32_t swar_zero_bytes(uint32_t x) {  // 0x80 where a byte of x is 0
   return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
 }
 
-// flags of 4 bases: bit 0 valid, 1 hq, 2 code bit 0, 3 code bit 1 of each byte
-__device__ __forceinline__ uint32_t swar_base_flags(uint32_t c, uint32_t q, uint32_t thr_low7, bool thr_neg) {
+// flags of 4 bytes: bit 0 valid, 1 hq, 2 code bit 0, 3 code bit 1 of each byte
+__device__ __forceinline__ uint32_t swar_byte_flags(uint32_t c, uint32_t thr_low7, bool thr_neg) {
   const uint32_t u = c & 0xDFDFDFDFu, e = u ^ 0x41414141u;
   const uint32_t z = swar_zero_bytes(e & 0xFDFDFDFDu) | swar_zero_bytes(e ^ 0x06060606u) | swar_zero_bytes(e ^ 0x15151515u);
   const uint32_t vm = (z - (z >> 7)) | z;  // 0xFF per valid byte
   const uint32_t code2 = ((u << 1) ^ u) & 0x0C0C0C0Cu;
-  // signed q >= t  <=>  unsigned (q ^ 0x80) >= (t ^ 0x80); thr_low7 / thr_neg describe t ^ 0x80
-  const uint32_t a = q ^ 0x80808080u;
+  // signed c >= t  <=>  unsigned (c ^ 0x80) >= (t ^ 0x80); thr_low7 / thr_neg describe t ^ 0x80
+  const uint32_t a = c ^ 0x80808080u;
   const uint32_t r = (a | 0x80808080u) - thr_low7;  // bit 7: low 7 bits of a >= low 7 bits of the threshold
   const uint32_t ge = thr_neg ? (a & r) : (a | r);
-  return (code2 | ((ge >> 6) & 0x02020202u) | 0x01010101u) & vm;
+  return ((code2 | 0x01010101u) & vm) | ((ge >> 6) & 0x02020202u);
 }
 
-#define QPK_UNROLL 2
+// flags of 8 bytes (two dwords) -> byte p = plane p (v, h, l0, l1) of the 8 bytes, by two delta swaps
+__device__ __forceinline__ uint32_t swar_transpose8(uint32_t f_lo, uint32_t f_hi) {
+  uint32_t g = f_lo | (f_hi << 4);
+  uint32_t t = ((g >> 7) ^ g) & 0x00AA00AAu;
+  g ^= t ^ (t << 7);
+  t = ((g >> 14) ^ g) & 0x0000CCCCu;
+  g ^= t ^ (t << 14);
+  return g;
+}
 
-__global__ __launch_bounds__(256) void k_pack_planes(const uint8_t* __restrict__ buf, uint32_t buf_len,
-                                                     const uint4* __restrict__ blk_desc,
-                                                     const uint32_t* __restrict__ blk_prefix,
-                                                     const qh_meta* __restrict__ meta, uint8_t* __restrict__ planes,
+// a lane per 16 bytes of text -> 16 bits of each plane; 1 KiB of text per wave and round
+__global__ __launch_bounds__(256) void k_text_planes(const uint8_t* __restrict__ buf, size_t len,
+                                                     uint16_t* __restrict__ planes, size_t plane_halfwords,
                                                      int min_qual) {
-  if (meta->format_err) return;
-  const uint64_t nunits = (uint64_t)blk_prefix[meta->nrec] * 8;  // 8 bases each
   const uint32_t tb = ((uint32_t)(int8_t)min_qual ^ 0x80u) & 0xFFu;
   const uint32_t thr_low7 = (tb & 0x7Fu) * 0x01010101u;
   const bool thr_neg = (tb & 0x80u) != 0;
-  const uint32_t last_dw = (buf_len - 1) & ~3u;  // last dword that holds a byte of the chunk
-  const uint32_t* __restrict__ words = reinterpret_cast<const uint32_t*>(buf);
-  const uint64_t stride = (uint64_t)gridDim.x * 256;
-  uint64_t u0 = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  uint4 dn[QPK_UNROLL];
-#pragma unroll
-  for (int r = 0; r < QPK_UNROLL; ++r) dn[r] = u0 + r * stride < nunits ? blk_desc[(u0 + r * stride) >> 3] : make_uint4(0, 0, 0, 0);
-  for (; u0 < nunits; u0 += QPK_UNROLL * stride) {
-    uint4 d[QPK_UNROLL];
-    uint32_t sw[QPK_UNROLL][3], qw[QPK_UNROLL][3];
-#pragma unroll
-    for (int r = 0; r < QPK_UNROLL; ++r) {
-      d[r] = dn[r];
-      const uint32_t off = (uint32_t)((u0 + r * stride) & 7) * 8;
-      const uint32_t sa = d[r].x + off, qa = d[r].y + off;
-      // three aligned dwords cover the 8 bytes at any alignment; dwords past the chunk are clamped
-      // (their bytes lie beyond the block's end and are masked below)
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const uint32_t s_at = (sa & ~3u) + 4 * i, q_at = (qa & ~3u) + 4 * i;
-        sw[r][i] = words[(s_at < last_dw ? s_at : last_dw) >> 2];
-        qw[r][i] = words[(q_at < last_dw ? q_at : last_dw) >> 2];
-      }
-    }
-    // descriptors of the next round while these loads are in flight
-#pragma unroll
-    for (int r = 0; r < QPK_UNROLL; ++r) {
-      const uint64_t un = u0 + (QPK_UNROLL + r) * stride;
-      dn[r] = un < nunits ? blk_desc[un >> 3] : make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < QPK_UNROLL; ++r) {
-      const uint64_t u = u0 + r * stride;
-      if (u >= nunits) break;
-      const uint32_t t8 = (uint32_t)(u & 7), off = t8 * 8;
-      const uint32_t sa = d[r].x + off, qa = d[r].y + off;
-      const uint32_t n = d[r].z > off ? (d[r].z - off < 8 ? d[r].z - off : 8) : 0;  // bases of the block in this unit
-      const uint32_t c_lo = __builtin_amdgcn_alignbyte(sw[r][1], sw[r][0], sa & 3u);
-      const uint32_t c_hi = __builtin_amdgcn_alignbyte(sw[r][2], sw[r][1], sa & 3u);
-      const uint32_t q_lo = __builtin_amdgcn_alignbyte(qw[r][1], qw[r][0], qa & 3u);
-      const uint32_t q_hi = __builtin_amdgcn_alignbyte(qw[r][2], qw[r][1], qa & 3u);
-      const uint64_t keep = n ? ~0ull >> (64 - 8 * n) : 0ull;
-      const uint32_t f_lo = swar_base_flags(c_lo, q_lo, thr_low7, thr_neg) & (uint32_t)keep;
-      const uint32_t f_hi = swar_base_flags(c_hi, q_hi, thr_low7, thr_neg) & (uint32_t)(keep >> 32);
-      // g: byte i = flags of base i (low nibble) and base i+4 (high nibble); transpose to
-      // byte p = plane p of the 8 bases
-      uint32_t g = f_lo | (f_hi << 4);
-      uint32_t t = ((g >> 7) ^ g) & 0x00AA00AAu;
-      g ^= t ^ (t << 7);
-      t = ((g >> 14) ^ g) & 0x0000CCCCu;
-      g ^= t ^ (t << 14);
-      uint8_t* o = planes + (u >> 3) * 32 + t8;
-      o[0] = (uint8_t)g;
-      o[8] = (uint8_t)(g >> 8);
-      o[16] = (uint8_t)(g >> 16);
-      o[24] = (uint8_t)(g >> 24);
-    }
+  const size_t nunits = (len + 15) / 16;
+  for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < nunits; u += (size_t)gridDim.x * 256) {
+    const uint4 x = load16_guarded(buf, u * 16, len);
+    const uint32_t g0 = swar_transpose8(swar_byte_flags(x.x, thr_low7, thr_neg), swar_byte_flags(x.y, thr_low7, thr_neg));
+    const uint32_t g1 = swar_transpose8(swar_byte_flags(x.z, thr_low7, thr_neg), swar_byte_flags(x.w, thr_low7, thr_neg));
+    // halfword of plane p = byte p of g0 | byte p of g1 << 8
+    const uint32_t vh = __builtin_amdgcn_perm(g1, g0, 0x05010400u);   // {g0.b0, g1.b0, g0.b1, g1.b1}
+    const uint32_t ll = __builtin_amdgcn_perm(g1, g0, 0x07030602u);   // {g0.b2, g1.b2, g0.b3, g1.b3}
+    planes[u] = (uint16_t)vh;
+    planes[plane_halfwords + u] = (uint16_t)(vh >> 16);
+    planes[2 * plane_halfwords + u] = (uint16_t)ll;
+    planes[3 * plane_halfwords + u] = (uint16_t)(ll >> 16);
   }
 }
 
-void qh_launch_fastq_prepare(const uint8_t* buf, size_t buf_len, const uint4* recs, uint32_t rec_cap, const qh_meta* meta,
-                             const qh_geom& g, const qh_fastq_aux& a, uint64_t max_blocks, hipStream_t s) {
+void qh_launch_text_planes(const uint8_t* buf, size_t len, const qh_geom& g, const qh_fastq_aux& a, hipStream_t s) {
+  if (!len) return;
+  const size_t nunits = (len + 15) / 16;
+  size_t wgs = (nunits + 255) / 256;
+  if (wgs > 256 * 8 * 4) wgs = 256 * 8 * 4;
+  hipLaunchKernelGGL(k_text_planes, dim3((unsigned)wgs), dim3(256), 0, s, buf, len, reinterpret_cast<uint16_t*>(a.planes),
+                     a.plane_words * 4, g.min_qual);
+}
+
+void qh_launch_segments(const uint4* recs, uint32_t rec_cap, const qh_meta* meta, const qh_geom& g,
+                        const qh_fastq_aux& a, hipStream_t s) {
   const uint32_t ntiles = (rec_cap + RB_TILE - 1) / RB_TILE;
-  hipLaunchKernelGGL(k_rec_blocks_sum, dim3(ntiles), dim3(256), 0, s, recs, meta, a.tile_sums, ntiles, (uint32_t)g.k);
-  hipLaunchKernelGGL(k_scan_u32, dim3(2), dim3(1024), 0, s, a.tile_sums, ntiles);
-  hipLaunchKernelGGL(k_rec_blocks_apply, dim3(ntiles), dim3(256), 0, s, recs, meta, a.tile_sums, ntiles, (uint32_t)g.k,
-                     a.blk_prefix, a.blk_desc, a.seg_desc);
-  uint64_t wgs = (max_blocks * 8 + 256 * QPK_UNROLL - 1) / (256 * QPK_UNROLL);
-  if (wgs > 256 * 8 * 2) wgs = 256 * 8 * 2;  // 8 workgroups of 256 threads fill a CU; two rounds of them
-  if (wgs < 1) wgs = 1;
-  hipLaunchKernelGGL(k_pack_planes, dim3((unsigned)wgs), dim3(256), 0, s, buf, (uint32_t)buf_len, a.blk_desc, a.blk_prefix,
-                     meta, reinterpret_cast<uint8_t*>(a.planes), g.min_qual);
+  hipLaunchKernelGGL(k_rec_segs_sum, dim3(ntiles), dim3(256), 0, s, recs, meta, a.tile_sums, (uint32_t)g.k);
+  hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, a.tile_sums, ntiles);
+  hipLaunchKernelGGL(k_rec_segs_apply, dim3(ntiles), dim3(256), 0, s, recs, meta, a.tile_sums, (uint32_t)g.k, a.seg_desc);
 }
 
 // ------------------------------------------------------------- LDS-staged multi-split
@@ -272,9 +211,10 @@ struct qp_params {
   qh_meta* meta;
   int check_owner;     // drop (and count) items whose owner shard is not g.shard_id
   int count_instances; // add emitted items to meta->instances / hq_instances
-  // SRC_FASTQ: the chunk as bit planes + segment descriptors (qh_launch_fastq_prepare)
+  // SRC_FASTQ: the chunk as text planes + segment descriptors (qh_launch_text_planes / _segments)
   const uint64_t* planes;
-  const uint2* seg_desc;
+  uint64_t plane_words;  // words per plane
+  const uint4* seg_desc;
   const uint32_t* seg_total;
   // SRC_ITEMS: input bucket b = blockIdx.y holds in[b * in_cap ...], in_counts[b] items (or in_n when in_counts == 0)
   const uint64_t* in;
@@ -328,17 +268,23 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
   // tile t is sorted and written out (one workgroup per CU: nothing else would hide the latency).
   // FASTQ: a lane per segment; its descriptor is fetched two tiles ahead, its two plane blocks
   // (64 bytes) one tile ahead.
-  uint2 sd_cur = make_uint2(0, 0), sd_next = make_uint2(0, 0);
-  uint4 pl[4];
+  uint4 sd_cur = make_uint4(0, 0, 0, 0), sd_next = make_uint4(0, 0, 0, 0);
+  uint4 pl[4];  // words j, j+1 of the v, l0, l1 planes at the sequence offset and of h at the quality offset
   uint64_t raw[QP_BLOCKS_PER_WAVE];
-  auto load_sdesc = [&](uint64_t tile) -> uint2 {
+  auto load_sdesc = [&](uint64_t tile) -> uint4 {
     const uint64_t sidx = tile * QP_THREADS + tid;
-    return sidx < nseg ? p.seg_desc[sidx] : make_uint2(0, 0);
+    return sidx < nseg ? p.seg_desc[sidx] : make_uint4(0, 0, 0, 0);
   };
-  auto issue_planes = [&](const uint2& sd) {
-    const uint4* q = reinterpret_cast<const uint4*>(p.planes) + 2 * (size_t)sd.x;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) pl[i] = q[i];
+  auto load2 = [&](const uint64_t* q) -> uint4 {  // two consecutive words, 8-byte aligned
+    const uint2 a = *reinterpret_cast<const uint2*>(q), b = *reinterpret_cast<const uint2*>(q + 1);
+    return make_uint4(a.x, a.y, b.x, b.y);
+  };
+  auto issue_planes = [&](const uint4& sd) {
+    const uint64_t* ps = p.planes + (sd.x >> 6);
+    pl[0] = load2(ps);
+    pl[1] = load2(ps + 2 * p.plane_words);
+    pl[2] = load2(ps + 3 * p.plane_words);
+    pl[3] = load2(p.planes + p.plane_words + (sd.y >> 6));
   };
   auto issue_items = [&](uint64_t tile) {
     const uint64_t j0 = tile * QP_TILE_ITEMS + (uint64_t)wave * (QP_BLOCKS_PER_WAVE * 64) + lane;
@@ -367,16 +313,16 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
 
     if (SRC == QP_SRC_FASTQ) {
       // create_database.cc:64-92 for the segment's k-mers: no rolling registers, every k-mer is a
-      // k-bit window of the planes. w* hold positions a .. a+63 of the read (bit i = position a+i).
-      const uint32_t o = sd_cur.y & 63u, cnt = (sd_cur.y >> 8) & 63u;
+      // k-bit window of the planes. w* hold bases a .. a+63 of the read (bit i = base a+i): v, l0, l1
+      // from the sequence bytes, h from the quality bytes.
+      const uint32_t o = sd_cur.x & 63u, oq = sd_cur.y & 63u, cnt = sd_cur.z;
       if (cnt) {
         const uint32_t kones = (uint32_t)((1ull << g.k) - 1);
-        auto fun = [&](uint32_t lo0, uint32_t lo1, uint32_t hi0, uint32_t hi1) -> uint64_t {
-          const uint64_t lo = ((uint64_t)lo1 << 32) | lo0, hi = ((uint64_t)hi1 << 32) | hi0;
-          return (lo >> o) | ((hi << 1) << (63 - o));
+        auto fun = [&](const uint4& w2, uint32_t sh) -> uint64_t {
+          const uint64_t lo = ((uint64_t)w2.y << 32) | w2.x, hi = ((uint64_t)w2.w << 32) | w2.z;
+          return (lo >> sh) | ((hi << 1) << (63 - sh));
         };
-        const uint64_t wv = fun(pl[0].x, pl[0].y, pl[2].x, pl[2].y), wh = fun(pl[0].z, pl[0].w, pl[2].z, pl[2].w);
-        const uint64_t w0 = fun(pl[1].x, pl[1].y, pl[3].x, pl[3].y), w1 = fun(pl[1].z, pl[1].w, pl[3].z, pl[3].w);
+        const uint64_t wv = fun(pl[0], o), w0 = fun(pl[1], o), w1 = fun(pl[2], o), wh = fun(pl[3], oq);
         // forward orientation: bit-reversed planes, aligned so that the newest base of k-mer j sits
         // at bit QP_SEG-1-j
         const int sh0 = 64 - g.k - (QP_SEG - 1);
@@ -516,8 +462,8 @@ void qh_launch_partition_fastq(const qh_fastq_aux& a, uint32_t rec_cap, qh_meta*
                                const qh_part_dst& d, int check_owner, hipStream_t s) {
   qp_params p = {};
   fill_common(p, d, meta, check_owner, 1);
-  p.planes = a.planes; p.seg_desc = a.seg_desc;
-  p.seg_total = a.tile_sums + 2 * ((rec_cap + RB_TILE - 1) / RB_TILE) + 1;
+  p.planes = a.planes; p.plane_words = a.plane_words; p.seg_desc = a.seg_desc;
+  p.seg_total = a.tile_sums + (rec_cap + RB_TILE - 1) / RB_TILE;
   hipLaunchKernelGGL(k_partition<QP_SRC_FASTQ>, dim3(256), dim3(QP_THREADS), 0, s, p, g);
 }
 
