@@ -156,9 +156,21 @@ extern "C" int qh_build_set_stream(qh_build* h, void* hip_stream) {
 
 // -------------------------------------------------------------- growth / sync
 
+// qh_build_reset defers the clearing of the table: a partitioned chunk writes every window anyway.
+// Everything else that reads or updates the table clears it first.
+static int materialize(qh_build* h) {
+  if (!h->zero_pending) return QH_OK;
+  QH_HIP(hipSetDevice(h->device));
+  QH_HIP(hipMemsetAsync(h->table, 0, (size_t)8 << h->g.lsize, h->stream));
+  h->zero_pending = false;
+  return QH_OK;
+}
+
 // the table-doubling half of handle_full_ary (mer_database.hpp:142-184): allocate a
 // table of at least 2^target_lsize slots, re-insert every key carrying its value
 static int grow_table(qh_build* h, int target_lsize) {
+  int mrc = materialize(h);
+  if (mrc) return mrc;
   uint64_t* new_table = nullptr;
   qh_geom ng;
   for (int lsize = target_lsize;; ++lsize) {
@@ -390,9 +402,11 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
     timing_end(h, 2);
   }
   timing_begin(h, 3);
-  qh_launch_window_build(h->table, g, h->d_bins[1], capw, h->d_bin_counts[1], nw, h->table_dirty ? 1 : 0, spill,
+  qh_launch_window_build(h->table, g, h->d_bins[1], capw, h->d_bin_counts[1], nw,
+                         (h->table_dirty ? 1 : 0) | (h->zero_pending ? 2 : 0), spill,
                          spill_cap, h->d_meta, h->stream);
   timing_end(h, 3);
+  h->zero_pending = false;  // every window has been written
   // items that overflowed a bucket or a window's reprobe limit: plain global-CAS insertion
   qh_launch_insert_items(spill, spill_cap, reinterpret_cast<const unsigned long long*>(&h->d_meta->spill_count), 0, 1,
                          h->d_meta, g, h->table, h->d_ovf[cur], h->ovf_cap[cur] / 8, h->stream);
@@ -424,6 +438,7 @@ extern "C" int qh_build_add_fastq_device(qh_build* h, const void* dev_buf, size_
     src.max_bases = len / 2;
     if ((rc = run_partitioned(h, src, len / 2))) return rc;
   } else {
+    if ((rc = materialize(h))) return rc;
     timing_begin(h);
     qh_launch_build_direct((const uint8_t*)dev_buf, h->d_recs, h->d_meta, h->g, h->table, h->d_ovf[h->cur_ovf],
                            h->ovf_cap[h->cur_ovf] / 8, h->stream);
@@ -477,6 +492,7 @@ static int submit_records(qh_build* h, const uint8_t* dev_buf, size_t buf_len, c
     src.max_bases = max_items;
     if ((rc = run_partitioned(h, src, max_items))) return rc;
   } else {
+    if ((rc = materialize(h))) return rc;
     timing_begin(h);
     qh_launch_build_direct(dev_buf, h->d_recs, h->d_meta, h->g, h->table, h->d_ovf[h->cur_ovf],
                            h->ovf_cap[h->cur_ovf] / 8, h->stream);
@@ -701,6 +717,7 @@ static int add_items_device(qh_build* h, const uint64_t* dev_items, size_t n, in
     src.hashed = hashed;
     if ((rc = run_partitioned(h, src, n))) return rc;
   } else {
+    if ((rc = materialize(h))) return rc;
     timing_begin(h);
     qh_launch_insert_items(dev_items, n, nullptr, 1, hashed, h->d_meta, h->g, h->table, h->d_ovf[h->cur_ovf], h->ovf_cap[h->cur_ovf] / 8, h->stream);
     timing_end(h);
@@ -785,7 +802,7 @@ extern "C" int qh_build_reset(qh_build* h) {
   if (!h) return qh_fail(QH_EBADARG, "null handle");
   if (h->pending) { int rc = qh_build_sync(h); if (rc && rc != QH_EFORMAT) return rc; }
   QH_HIP(hipSetDevice(h->device));
-  QH_HIP(hipMemsetAsync(h->table, 0, (size_t)8 << h->g.lsize, h->stream));
+  h->zero_pending = true;  // cleared by the next partitioned chunk's window pass, or by materialize()
   const uint64_t slots = h->st.slots, grows = h->st.grows;
   memset(&h->st, 0, sizeof h->st);
   h->st.slots = slots; h->st.grows = grows;
@@ -816,6 +833,7 @@ extern "C" int qh_build_write(qh_build* h, const char* path, int argc, const cha
 // the global atomic_bits_array image (word-aligned when slots % vpw == 0, else the
 // shard owner ORs its fields into shared boundary words -- single writer at a time).
 extern "C" int qh_build_write_shard(qh_build* h, const char* path, int argc, const char* const* argv, int write_header) {
+  if (h) { int mrc = materialize(h); if (mrc) return mrc; }
   if (!h || !path) return qh_fail(QH_EBADARG, "null argument");
   int rc = qh_build_sync(h);
   if (rc) return rc;
@@ -877,6 +895,7 @@ extern "C" int qh_build_write_shard(qh_build* h, const char* path, int argc, con
 }
 
 extern "C" int qh_build_dump(qh_build* h, uint64_t* mers, uint64_t* vals, uint64_t cap, uint64_t* n) {
+  if (h) { int mrc = materialize(h); if (mrc) return mrc; }
   if (!h || !n) return qh_fail(QH_EBADARG, "null argument");
   int rc = qh_build_sync(h);
   if (rc) return rc;
@@ -884,6 +903,7 @@ extern "C" int qh_build_dump(qh_build* h, uint64_t* mers, uint64_t* vals, uint64
 }
 
 extern "C" int qh_build_as_query(qh_build* h, qh_query** out) {
+  if (h) { int mrc = materialize(h); if (mrc) return mrc; }
   if (!h || !out) return qh_fail(QH_EBADARG, "null argument");
   int rc = qh_build_sync(h);
   if (rc) return rc;

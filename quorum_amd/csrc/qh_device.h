@@ -24,6 +24,49 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
 
+// Exclusive scan of v[0, n) in place by one workgroup of 1024 threads (part = 1024 words of LDS);
+// returns the total to every thread. Thread t owns the span [t * per, (t+1) * per): spans of up to
+// 32 values are held in registers so that their loads are all in flight together (a dependent
+// loop of global loads made these one-workgroup kernels cost 35 us).
+__device__ __forceinline__ uint32_t block_scan_u32(uint32_t* __restrict__ v, uint32_t n, uint32_t* part) {
+  const uint32_t per = (n + 1023) / 1024;
+  const uint32_t b = threadIdx.x * per;
+  uint32_t s = 0;
+  uint32_t c[32];
+  const bool small = per <= 32;
+  if (small) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) c[i] = ((uint32_t)i < per && b + i < n) ? v[b + i] : 0u;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s += c[i];
+  } else {
+    for (uint32_t i = b; i < b + per && i < n; ++i) s += v[i];
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (uint32_t o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan over the 1024 partials
+    const uint32_t x = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+    __syncthreads();
+    part[threadIdx.x] += x;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - s;  // exclusive prefix of this thread's span
+  if (small) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      if ((uint32_t)i < per && b + i < n) v[b + i] = run;
+      run += c[i];
+    }
+  } else {
+    for (uint32_t i = b; i < b + per && i < n; ++i) {
+      const uint32_t x = v[i];
+      v[i] = run;
+      run += x;
+    }
+  }
+  return part[1023];
+}
+
 // 16-bit mask of the bytes of v that equal '\n'
 __device__ __forceinline__ uint32_t nl_mask16(uint4 v) {
   uint32_t w[4] = {v.x, v.y, v.z, v.w};

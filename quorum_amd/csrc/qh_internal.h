@@ -25,6 +25,7 @@ struct qh_build {
   uint64_t* d_planes = nullptr;    size_t planes_cap = 0;   // bit planes of the chunk
   uint64_t* d_bins[2] = {nullptr, nullptr}; size_t bins_cap[2] = {0, 0};       // level-1 / window buckets (bytes)
   unsigned long long* d_bin_counts[2] = {nullptr, nullptr}; size_t bin_counts_cap[2] = {0, 0};
+  bool zero_pending = false;  // qh_build_reset left the clearing of the table to the next partitioned chunk
   bool table_dirty = false;   // the table holds entries (a window must be loaded before it is updated)
   int mode = 0;               // 0 auto, 1 direct global-CAS build, 2 radix-partitioned LDS build
   int level1_bits = -1;       // -1 auto: buckets of the first partition level (QH_LEVEL1_BITS)

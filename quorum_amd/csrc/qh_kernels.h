@@ -88,8 +88,10 @@ void qh_launch_partition_fastq(const qh_fastq_aux& a, uint32_t rec_cap, qh_meta*
 void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsigned long long* in_counts,
                                uint32_t in_count_stride, uint32_t n_in_buckets, uint64_t in_n, int in_hashed, qh_meta* meta, const qh_geom& g,
                                const qh_part_dst& d, int check_owner, int count_instances, hipStream_t s);
+// table_state: bit 0 = the table holds entries (load each window first), bit 1 = the table has not
+// been cleared yet (windows without items must be zeroed here)
 void qh_launch_window_build(uint64_t* table, const qh_geom& g, const uint64_t* items, uint64_t cap,
-                            const unsigned long long* counts, uint32_t n_windows, int table_dirty, uint64_t* spill,
+                            const unsigned long long* counts, uint32_t n_windows, int table_state, uint64_t* spill,
                             uint64_t spill_cap, qh_meta* meta, hipStream_t s);
 
 // --- read side ------------------------------------------------------------------------

@@ -39,27 +39,9 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ tile
                                                      const uint8_t* __restrict__ buf, size_t len,
                                                      uint32_t rec_cap, qh_meta* __restrict__ meta) {
   __shared__ uint32_t part[1024];
-  const uint32_t per = (ntiles + 1023) / 1024;
-  const uint32_t b = threadIdx.x * per;
-  uint32_t s = 0;
-  for (uint32_t i = b; i < b + per && i < ntiles; ++i) s += tile_counts[i];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  // Hillis-Steele inclusive scan over 1024 partials
-  for (uint32_t o = 1; o < 1024; o <<= 1) {
-    uint32_t v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
-    __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
-  }
-  uint32_t run = part[threadIdx.x] - s;  // exclusive prefix of this thread's span
-  for (uint32_t i = b; i < b + per && i < ntiles; ++i) {
-    const uint32_t c = tile_counts[i];
-    tile_counts[i] = run;
-    run += c;
-  }
+  const uint32_t total_lines = block_scan_u32(tile_counts, ntiles, part);
   if (threadIdx.x == 1023) {
-    uint32_t lines = part[1023];
+    uint32_t lines = total_lines;
     if (len > 0 && buf[len - 1] != '\n') ++lines;  // last line without '\n'
     uint32_t err = 0;
     if (lines & 3u) err |= QH_FMT_LINES_MOD4;

@@ -65,25 +65,8 @@ __global__ __launch_bounds__(256) void k_rec_segs_sum(const uint4* __restrict__ 
 // exclusive scan of n u32 values in place by one workgroup; the total goes to v[n]
 __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t* __restrict__ v, uint32_t n) {
   __shared__ uint32_t part[1024];
-  const uint32_t per = (n + 1023) / 1024;
-  const uint32_t b = threadIdx.x * per;
-  uint32_t s = 0;
-  for (uint32_t i = b; i < b + per && i < n; ++i) s += v[i];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  for (uint32_t o = 1; o < 1024; o <<= 1) {
-    const uint32_t x = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
-    __syncthreads();
-    part[threadIdx.x] += x;
-    __syncthreads();
-  }
-  uint32_t run = part[threadIdx.x] - s;
-  for (uint32_t i = b; i < b + per && i < n; ++i) {
-    const uint32_t c = v[i];
-    v[i] = run;
-    run += c;
-  }
-  if (threadIdx.x == 1023) v[n] = part[1023];
+  const uint32_t total = block_scan_u32(v, n, part);
+  if (threadIdx.x == 1023) v[n] = total;
 }
 
 __global__ __launch_bounds__(256) void k_rec_segs_apply(const uint4* __restrict__ recs, const qh_meta* __restrict__ meta,
@@ -513,7 +496,13 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
   const uint32_t w = blockIdx.x;
   uint64_t n = counts[w];
   if (n > cap) n = cap;
-  if (n == 0) return;  // nothing to add: the window stays as it is
+  if (n == 0) {  // nothing to add: the window stays as it is, or is cleared when the table's clearing was left to us
+    if (table_dirty & 2) {
+      uint4* z = reinterpret_cast<uint4*>(table + ((uint64_t)w << QH_WINDOW_BITS));
+      for (uint32_t i = threadIdx.x; i < (1u << QH_WINDOW_BITS) / 2; i += QP_THREADS) z[i] = make_uint4(0, 0, 0, 0);
+    }
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // this wave's segment of the bucket
@@ -527,7 +516,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
   uint4* tw = reinterpret_cast<uint4*>(table + ((uint64_t)w << QH_WINDOW_BITS));
   uint4* lw = reinterpret_cast<uint4*>(win);
   const uint32_t nvec = (1u << QH_WINDOW_BITS) / 2;  // 16-byte pieces
-  if (table_dirty) {
+  if (table_dirty & 1) {
 #pragma unroll
     for (uint32_t i = 0; i < nvec / QP_THREADS; ++i) lw[i * QP_THREADS + tid] = tw[i * QP_THREADS + tid];
   } else {
@@ -702,7 +691,13 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_count(uint64_t* __restric
   const uint32_t w = blockIdx.x;
   uint64_t n = counts[w];
   if (n > cap) n = cap;
-  if (n == 0) return;  // nothing to add: the window stays as it is
+  if (n == 0) {  // nothing to add: the window stays as it is, or is cleared when the table's clearing was left to us
+    if (table_dirty & 2) {
+      uint4* z = reinterpret_cast<uint4*>(table + ((uint64_t)w << QH_WINDOW_BITS));
+      for (uint32_t i = threadIdx.x; i < (1u << QH_WINDOW_BITS) / 2; i += QP_THREADS) z[i] = make_uint4(0, 0, 0, 0);
+    }
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t seg = (uint32_t)((n + QP_WAVES - 1) / QP_WAVES);
@@ -727,7 +722,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_count(uint64_t* __restric
     const uint64_t v = ((c < g.max_val ? c : g.max_val) << 1) | (hc ? 1u : 0u);
     return t ? (t << g.vbits) | v : 0ull;
   };
-  if (table_dirty) {
+  if (table_dirty & 1) {
 #pragma unroll
     for (uint32_t i = 0; i < nvec / QP_THREADS; ++i) {
       const uint4 x = tw[i * QP_THREADS + tid];
