@@ -138,7 +138,7 @@ extern "C" void qh_build_destroy(qh_build* h) {
   if (!h) return;
   hipError_t e = hipSetDevice(h->device); (void)e;
   if (h->stream) { e = hipStreamSynchronize(h->stream); (void)e; }
-  void* ptrs[] = {h->table, h->d_meta, h->d_chunk, h->d_recs, h->d_tiles, h->d_ovf[0], h->d_ovf[1], h->d_items, h->d_shard_counts, h->d_rbsums, h->d_segdesc, h->d_planes,
+  void* ptrs[] = {h->table, h->d_meta, h->d_chunk, h->d_recs, h->d_tiles, h->d_ovf[0], h->d_ovf[1], h->d_items, h->d_shard_counts, h->d_rbsums, h->d_segdesc, h->d_planes, h->d_nlplane,
                   h->d_bins[0], h->d_bins[1], h->d_bin_counts[0], h->d_bin_counts[1]};
   for (void* p : ptrs) if (p) { e = hipFree(p); (void)e; }
   if (h->h_meta) { e = hipHostFree(h->h_meta); (void)e; }
@@ -340,6 +340,7 @@ static int fastq_aux(qh_build* h, size_t buf_len, size_t rec_cap, size_t max_bas
 struct part_source {
   const uint8_t* fastq = nullptr;    // FASTQ chunk whose record table is in h->d_recs
   size_t fastq_len = 0;              // bytes of that chunk
+  bool planes_ready = false;         // the text planes were made by the indexing pass
   size_t rec_cap = 0;
   size_t max_bases = 0;              // upper bound of the chunk's bases
   const uint64_t* items = nullptr;   // or an item list
@@ -385,7 +386,7 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
     qh_fastq_aux aux;
     if ((rc = fastq_aux(h, src.fastq_len, src.rec_cap, src.max_bases, &aux))) return rc;
     timing_begin(h, 0);
-    qh_launch_text_planes(src.fastq, src.fastq_len, g, aux, h->stream);
+    if (!src.planes_ready) qh_launch_text_planes(src.fastq, src.fastq_len, g, aux, h->stream);
     qh_launch_segments(h->d_recs, (uint32_t)src.rec_cap, h->d_meta, g, aux, h->stream);
     timing_end(h, 0);
     timing_begin(h, 1);
@@ -429,10 +430,17 @@ extern "C" int qh_build_add_fastq_device(qh_build* h, const void* dev_buf, size_
   const size_t rec_cap = len / 16 + 16;
   if ((rc = ensure((void**)&h->d_tiles, &h->tile_cap, (ntiles + 1) * 4, "tile counts"))) return rc;
   if ((rc = ensure((void**)&h->d_recs, &h->rec_cap, rec_cap * 16, "record table"))) return rc;
-  qh_launch_index_fastq((const uint8_t*)dev_buf, len, h->d_tiles, h->d_recs, (uint32_t)rec_cap, h->d_meta, h->stream);
-  if (use_partition(h, len / 2)) {
+  if ((rc = ensure((void**)&h->d_nlplane, &h->nlplane_cap, (len / 16 + 2) * 8, "newline plane"))) return rc;
+  const bool part = use_partition(h, len / 2);
+  qh_fastq_aux aux;
+  if (part && (rc = fastq_aux(h, len, rec_cap, len / 2, &aux))) return rc;
+  // one pass over the text: newline plane for the record table and, for the partitioned build, the text planes
+  qh_launch_index_fastq((const uint8_t*)dev_buf, len, h->d_tiles, h->d_nlplane, h->d_recs, (uint32_t)rec_cap, h->d_meta,
+                        part ? &aux : nullptr, h->g.min_qual, h->stream);
+  if (part) {
     part_source src;
     src.fastq = (const uint8_t*)dev_buf;
+    src.planes_ready = true;
     src.fastq_len = len;
     src.rec_cap = rec_cap;
     src.max_bases = len / 2;
@@ -762,10 +770,11 @@ extern "C" int qh_build_extract_partitioned_device(qh_build* h, const void* dev_
   const size_t rec_cap = len / 16 + 16;
   if ((rc = ensure((void**)&h->d_tiles, &h->tile_cap, (ntiles + 1) * 4, "tile counts"))) return rc;
   if ((rc = ensure((void**)&h->d_recs, &h->rec_cap, rec_cap * 16, "record table"))) return rc;
-  qh_launch_index_fastq((const uint8_t*)dev_buf, len, h->d_tiles, h->d_recs, (uint32_t)rec_cap, h->d_meta, h->stream);
+  if ((rc = ensure((void**)&h->d_nlplane, &h->nlplane_cap, (len / 16 + 2) * 8, "newline plane"))) return rc;
   qh_fastq_aux aux;
   if ((rc = fastq_aux(h, len, rec_cap, len / 2, &aux))) return rc;
-  qh_launch_text_planes((const uint8_t*)dev_buf, len, h->g, aux, h->stream);
+  qh_launch_index_fastq((const uint8_t*)dev_buf, len, h->d_tiles, h->d_nlplane, h->d_recs, (uint32_t)rec_cap, h->d_meta,
+                        &aux, h->g.min_qual, h->stream);
   qh_launch_segments(h->d_recs, (uint32_t)rec_cap, h->d_meta, h->g, aux, h->stream);
   // bucket = owner shard = low shard_bits of the hash; a bucket that overflows is an error here
   qh_part_dst dst = {dev_out, cap_per_shard, (unsigned long long*)dev_counts, 0, h->g.shard_bits, 0, nullptr, 0, 1};

@@ -16,6 +16,7 @@ struct qh_build {
   uint8_t* d_chunk = nullptr;  size_t chunk_cap = 0;  // staging of host-fed chunks
   uint4* d_recs = nullptr;     size_t rec_cap = 0;    // record table of the chunk
   uint32_t* d_tiles = nullptr; size_t tile_cap = 0;   // newline counts / prefix per tile
+  ushort4* d_nlplane = nullptr; size_t nlplane_cap = 0;  // newline bits per 16 chunk bytes (+ what follows them)
   uint64_t* d_ovf[2] = {nullptr, nullptr}; size_t ovf_cap[2] = {0, 0};  // overflow lists (bytes)
   uint64_t* d_items = nullptr; size_t items_cap = 0;  // staging of host-fed items
   uint64_t* d_shard_counts = nullptr;

@@ -17,16 +17,40 @@
 
 // ------------------------------------------------------- FASTQ chunk -> record table
 
-// pass 1: newlines per 16 KiB tile
-__global__ __launch_bounds__(QH_BLOCK) void k_count_newlines(const uint8_t* __restrict__ buf, size_t len,
-                                                             uint32_t* __restrict__ tile_counts) {
+// pass 1, the only pass over the chunk's text: newlines per 16 KiB tile, the newline plane (one
+// bit per byte, 16 bits per lane) that pass 3 works from, and -- when the chunk goes through the
+// partitioned build -- the four text planes of qh_partition.hip
+__global__ __launch_bounds__(QH_BLOCK) void k_index_text(const uint8_t* __restrict__ buf, size_t len,
+                                                         uint32_t* __restrict__ tile_counts,
+                                                         ushort4* __restrict__ nl_plane,
+                                                         uint16_t* __restrict__ planes, size_t plane_halfwords,
+                                                         int min_qual) {
   __shared__ uint32_t wsum[QH_BLOCK / 64];
   const size_t tile_base = (size_t)blockIdx.x * QH_TILE_BYTES;
+  const qh_swar_thr thr = qh_swar_threshold(min_qual);
   uint32_t cnt = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const size_t off = tile_base + ((size_t)j * QH_BLOCK + threadIdx.x) * 16;
-    if (off < len) cnt += __popc(nl_mask16(load16_guarded(buf, off, len)));
+    if (off < len) {
+      const uint4 x = load16_guarded(buf, off, len);
+      const uint32_t m = nl_mask16(x);
+      cnt += __popc(m);
+      // what follows each newline: '@' (a header must) or '+' (a separator must); pass 3 knows which
+      const uint32_t w[5] = {x.x, x.y, x.z, x.w, off + 16 < len ? (uint32_t)buf[off + 16] : 0u};
+      uint32_t mm = m, m_at = 0, m_plus = 0;
+      while (mm) {
+        const int b = __ffs(mm) - 1;
+        mm &= mm - 1;
+        const int nb = b + 1, ws = nb >> 2;
+        const uint32_t d = ws == 0 ? w[0] : ws == 1 ? w[1] : ws == 2 ? w[2] : ws == 3 ? w[3] : w[4];
+        const uint32_t c = (d >> (8 * (nb & 3))) & 0xFFu;
+        m_at |= (uint32_t)(c == '@') << b;
+        m_plus |= (uint32_t)(c == '+') << b;
+      }
+      nl_plane[off >> 4] = make_ushort4((unsigned short)m, (unsigned short)m_at, (unsigned short)m_plus, 0);
+      if (planes) qh_store_text_planes(x, off >> 4, planes, plane_halfwords, thr);
+    }
   }
   cnt = wave_sum_u32(cnt);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
@@ -54,23 +78,22 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ tile
   }
 }
 
-// a newline at byte p ends line L: fill the matching field of record L/4 and
-// check the first byte of line L+1 ('@' for a header line, '+' for a separator)
-__device__ __forceinline__ void line_end(const uint8_t* __restrict__ buf, size_t len, uint32_t L,
-                                         uint32_t p, uint32_t* __restrict__ recs, uint32_t rec_cap,
-                                         qh_meta* __restrict__ meta) {
+// a newline at byte p ends line L: fill the matching field of record L/4 and check the first
+// byte of line L+1 ('@' for a header line, '+' for a separator); at / plus say what that byte is
+__device__ __forceinline__ void line_end(size_t len, uint32_t L, uint32_t p, bool at, bool plus,
+                                         uint32_t* __restrict__ recs, uint32_t rec_cap, qh_meta* __restrict__ meta) {
   const uint32_t r = L >> 2, t = L & 3u;
   if (r < rec_cap) recs[4 * (size_t)r + t] = (t & 1u) ? p : p + 1;  // x=seq_off y=seq_end z=qual_off w=qual_end
   if ((size_t)p + 1 < len) {
     const uint32_t nt = (L + 1) & 3u;
-    const uint8_t c = buf[p + 1];
-    if (nt == 0 && c != '@') { atomicOr(&meta->format_err, QH_FMT_NO_AT); atomicMin(&meta->first_bad, (L + 1) >> 2); }
-    if (nt == 2 && c != '+') { atomicOr(&meta->format_err, QH_FMT_NO_PLUS); atomicMin(&meta->first_bad, (L + 1) >> 2); }
+    if (nt == 0 && !at) { atomicOr(&meta->format_err, QH_FMT_NO_AT); atomicMin(&meta->first_bad, (L + 1) >> 2); }
+    if (nt == 2 && !plus) { atomicOr(&meta->format_err, QH_FMT_NO_PLUS); atomicMin(&meta->first_bad, (L + 1) >> 2); }
   }
 }
 
 // pass 3: every newline writes its field of the record table
 __global__ __launch_bounds__(QH_BLOCK) void k_fill_records(const uint8_t* __restrict__ buf, size_t len,
+                                                           const ushort4* __restrict__ nl_plane,
                                                            const uint32_t* __restrict__ tile_prefix,
                                                            uint32_t* __restrict__ recs, uint32_t rec_cap,
                                                            qh_meta* __restrict__ meta) {
@@ -82,7 +105,8 @@ __global__ __launch_bounds__(QH_BLOCK) void k_fill_records(const uint8_t* __rest
 #pragma unroll 1
   for (int j = 0; j < 4; ++j) {
     const size_t off = tile_base + ((size_t)j * QH_BLOCK + threadIdx.x) * 16;
-    uint32_t m = off < len ? nl_mask16(load16_guarded(buf, off, len)) : 0;
+    const ushort4 nl = off < len ? nl_plane[off >> 4] : make_ushort4(0, 0, 0, 0);
+    uint32_t m = nl.x;
     const uint32_t c = __popc(m);
     // block exclusive scan of c
     uint32_t inc = c;
@@ -104,13 +128,13 @@ __global__ __launch_bounds__(QH_BLOCK) void k_fill_records(const uint8_t* __rest
     while (m) {
       const int bpos = __ffs(m) - 1;
       m &= m - 1;
-      line_end(buf, len, L++, (uint32_t)(off + bpos), recs, rec_cap, meta);
+      line_end(len, L++, (uint32_t)(off + bpos), (nl.y >> bpos) & 1, (nl.z >> bpos) & 1, recs, rec_cap, meta);
     }
     run += tot;
     __syncthreads();
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && len > 0 && buf[len - 1] != '\n')
-    line_end(buf, len, meta->n_lines - 1, (uint32_t)len, recs, rec_cap, meta);
+    line_end(len, meta->n_lines - 1, (uint32_t)len, true, true, recs, rec_cap, meta);
 }
 
 // pass 4: length checks; rewrites each record to {seq_off, len, qual_off, 0}
@@ -130,13 +154,16 @@ __global__ __launch_bounds__(QH_BLOCK) void k_validate_records(uint4* __restrict
   }
 }
 
-void qh_launch_index_fastq(const uint8_t* buf, size_t len, uint32_t* tile_counts, uint4* recs,
-                           uint32_t rec_cap, qh_meta* meta, hipStream_t s) {
+void qh_launch_index_fastq(const uint8_t* buf, size_t len, uint32_t* tile_counts, ushort4* nl_plane, uint4* recs,
+                           uint32_t rec_cap, qh_meta* meta, const qh_fastq_aux* planes, int min_qual, hipStream_t s) {
   const uint32_t ntiles = (uint32_t)((len + QH_TILE_BYTES - 1) / QH_TILE_BYTES);
-  if (ntiles) hipLaunchKernelGGL(k_count_newlines, dim3(ntiles), dim3(QH_BLOCK), 0, s, buf, len, tile_counts);
+  if (ntiles)
+    hipLaunchKernelGGL(k_index_text, dim3(ntiles), dim3(QH_BLOCK), 0, s, buf, len, tile_counts, nl_plane,
+                       planes ? reinterpret_cast<uint16_t*>(planes->planes) : nullptr,
+                       planes ? (size_t)planes->plane_words * 4 : 0, min_qual);
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_counts, ntiles, buf, len, rec_cap, meta);
   if (ntiles)
-    hipLaunchKernelGGL(k_fill_records, dim3(ntiles), dim3(QH_BLOCK), 0, s, buf, len, tile_counts,
+    hipLaunchKernelGGL(k_fill_records, dim3(ntiles), dim3(QH_BLOCK), 0, s, buf, len, nl_plane, tile_counts,
                        reinterpret_cast<uint32_t*>(recs), rec_cap, meta);
   hipLaunchKernelGGL(k_validate_records, dim3(1024), dim3(QH_BLOCK), 0, s, recs, meta);
 }

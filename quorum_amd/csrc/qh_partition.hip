@@ -110,55 +110,14 @@ __global__ __launch_bounds__(256) void k_rec_segs_apply(const uint4* __restrict_
   }
 }
 
-// SWAR over 4 bytes of text at a time: zero-byte tests on u ^ 'A' give validity, two shifts the
-// code, a biased subtract the signed quality compare.
-__device__ __forceinline__ uint32_t swar_zero_bytes(uint32_t x) {  // 0x80 where a byte of x is 0
-  return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
-}
-
-// flags of 4 bytes: bit 0 valid, 1 hq, 2 code bit 0, 3 code bit 1 of each byte
-__device__ __forceinline__ uint32_t swar_byte_flags(uint32_t c, uint32_t thr_low7, bool thr_neg) {
-  const uint32_t u = c & 0xDFDFDFDFu, e = u ^ 0x41414141u;
-  const uint32_t z = swar_zero_bytes(e & 0xFDFDFDFDu) | swar_zero_bytes(e ^ 0x06060606u) | swar_zero_bytes(e ^ 0x15151515u);
-  const uint32_t vm = (z - (z >> 7)) | z;  // 0xFF per valid byte
-  const uint32_t code2 = ((u << 1) ^ u) & 0x0C0C0C0Cu;
-  // signed c >= t  <=>  unsigned (c ^ 0x80) >= (t ^ 0x80); thr_low7 / thr_neg describe t ^ 0x80
-  const uint32_t a = c ^ 0x80808080u;
-  const uint32_t r = (a | 0x80808080u) - thr_low7;  // bit 7: low 7 bits of a >= low 7 bits of the threshold
-  const uint32_t ge = thr_neg ? (a & r) : (a | r);
-  return ((code2 | 0x01010101u) & vm) | ((ge >> 6) & 0x02020202u);
-}
-
-// flags of 8 bytes (two dwords) -> byte p = plane p (v, h, l0, l1) of the 8 bytes, by two delta swaps
-__device__ __forceinline__ uint32_t swar_transpose8(uint32_t f_lo, uint32_t f_hi) {
-  uint32_t g = f_lo | (f_hi << 4);
-  uint32_t t = ((g >> 7) ^ g) & 0x00AA00AAu;
-  g ^= t ^ (t << 7);
-  t = ((g >> 14) ^ g) & 0x0000CCCCu;
-  g ^= t ^ (t << 14);
-  return g;
-}
-
 // a lane per 16 bytes of text -> 16 bits of each plane; 1 KiB of text per wave and round
 __global__ __launch_bounds__(256) void k_text_planes(const uint8_t* __restrict__ buf, size_t len,
                                                      uint16_t* __restrict__ planes, size_t plane_halfwords,
                                                      int min_qual) {
-  const uint32_t tb = ((uint32_t)(int8_t)min_qual ^ 0x80u) & 0xFFu;
-  const uint32_t thr_low7 = (tb & 0x7Fu) * 0x01010101u;
-  const bool thr_neg = (tb & 0x80u) != 0;
+  const qh_swar_thr thr = qh_swar_threshold(min_qual);
   const size_t nunits = (len + 15) / 16;
-  for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < nunits; u += (size_t)gridDim.x * 256) {
-    const uint4 x = load16_guarded(buf, u * 16, len);
-    const uint32_t g0 = swar_transpose8(swar_byte_flags(x.x, thr_low7, thr_neg), swar_byte_flags(x.y, thr_low7, thr_neg));
-    const uint32_t g1 = swar_transpose8(swar_byte_flags(x.z, thr_low7, thr_neg), swar_byte_flags(x.w, thr_low7, thr_neg));
-    // halfword of plane p = byte p of g0 | byte p of g1 << 8
-    const uint32_t vh = __builtin_amdgcn_perm(g1, g0, 0x05010400u);   // {g0.b0, g1.b0, g0.b1, g1.b1}
-    const uint32_t ll = __builtin_amdgcn_perm(g1, g0, 0x07030602u);   // {g0.b2, g1.b2, g0.b3, g1.b3}
-    planes[u] = (uint16_t)vh;
-    planes[plane_halfwords + u] = (uint16_t)(vh >> 16);
-    planes[2 * plane_halfwords + u] = (uint16_t)ll;
-    planes[3 * plane_halfwords + u] = (uint16_t)(ll >> 16);
-  }
+  for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < nunits; u += (size_t)gridDim.x * 256)
+    qh_store_text_planes(load16_guarded(buf, u * 16, len), u, planes, plane_halfwords, thr);
 }
 
 void qh_launch_text_planes(const uint8_t* buf, size_t len, const qh_geom& g, const qh_fastq_aux& a, hipStream_t s) {
