@@ -165,7 +165,6 @@ struct qp_params {
   uint32_t in_count_stride;
   uint64_t in_n;
   int in_hashed;       // 0: (mer<<1|q) as the C ABI passes them, 1: (hash<<1|q)
-  int ablate;          // timing experiments only (QH_ABLATE): 16 no write-out, 32 no placement, 64 no histogram
 };
 
 enum { QP_SRC_FASTQ = 0, QP_SRC_ITEMS = 1 };
@@ -283,7 +282,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
             } else {
               ++n_inst; n_hq += q;
               it[j] = (h << 1) | q;
-              if (!(p.ablate & 64)) atomicAdd(&cursor[(uint32_t)(h >> p.bin_shift) & p.bin_mask], 1u);
+              atomicAdd(&cursor[(uint32_t)(h >> p.bin_shift) & p.bin_mask], 1u);
             }
           }
         }
@@ -345,10 +344,9 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
           offs[b] = run;
           cursor[b] = run;
           // reserve the bucket range now, look at the answer only after the placement pass
-          resv[e] = c[e] && !(p.ablate & 128)
-                        ? (uint32_t)atomicAdd(&p.out_counts[(((uint64_t)in_bucket << p.out_bin_shift) | b) * p.out_count_stride],
-                                              (unsigned long long)c[e])
-                        : 0u;
+          resv[e] = c[e] ? (uint32_t)atomicAdd(&p.out_counts[(((uint64_t)in_bucket << p.out_bin_shift) | b) * p.out_count_stride],
+                                               (unsigned long long)c[e])
+                         : 0u;
           run += c[e];
         }
       }
@@ -358,7 +356,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
     // ---- pass 2: place the items bucket-sorted into LDS
 #pragma unroll
     for (int i = 0; i < QP_BLOCKS_PER_WAVE; ++i) {
-      if (it[i] != QP_NONE && !(p.ablate & 32)) {
+      if (it[i] != QP_NONE) {
         const uint32_t b = (uint32_t)((it[i] >> 1) >> p.bin_shift) & p.bin_mask;
         sorted[atomicAdd(&cursor[b], 1u)] = it[i];
       }
@@ -369,7 +367,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
     __syncthreads();
 
     // ---- stream the tile out: consecutive lanes of one bucket write consecutive words
-    const uint32_t total = (p.ablate & 16) ? 0 : s_total;
+    const uint32_t total = s_total;
     for (uint32_t j = tid; j < total; j += QP_THREADS) {
       const uint64_t v = sorted[j];
       const uint32_t b = (uint32_t)((v >> 1) >> p.bin_shift) & p.bin_mask;
@@ -396,8 +394,6 @@ static void fill_common(qp_params& p, const qh_part_dst& d, qh_meta* meta, int c
   p.bin_shift = d.bin_shift; p.bin_mask = (1u << d.bin_bits) - 1; p.out_bin_shift = d.out_bin_shift;
   p.spill = d.spill; p.spill_cap = d.spill_cap; p.meta = meta;
   p.check_owner = check_owner; p.count_instances = count_instances;
-  static const int ablate = getenv("QH_ABLATE") ? atoi(getenv("QH_ABLATE")) : 0;
-  p.ablate = ablate;
 }
 
 void qh_launch_partition_fastq(const qh_fastq_aux& a, uint32_t rec_cap, qh_meta* meta, const qh_geom& g,
