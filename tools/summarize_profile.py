@@ -36,6 +36,21 @@ if os.path.exists(f):
     for r in csv.DictReader(open(f)):
         stats[r["Name"].split("(")[0]] = float(r["AverageNs"])
 json.dump({"per_kernel": traffic, "avg_ns": stats}, open("%s/traffic.json" % dst, "w"), indent=1, sort_keys=True)
+# what bench.py's roofline.traffic reads: HBM bytes per launch of each main kernel
+per = {}
+for k, t in traffic.items():
+    n = k.replace("void ", "")
+    if n.startswith(("k_partition", "k_window", "k_build_direct", "k_index_text")):
+        per[n] = t["fetch_bytes_x2"] + t["write_bytes"]
+if per:
+    old = {}
+    if os.path.exists("profiles/pmc_traffic.json"):
+        old = json.load(open("profiles/pmc_traffic.json")).get("per_kernel_hbm_bytes_per_launch", {})
+    old.update(per)
+    json.dump({"per_kernel_hbm_bytes_per_launch": old,
+               "source": "%s/traffic.json (kernels absent from that run keep their earlier figure): (TCC FETCH_SIZE*2 + WRITE_SIZE) KiB "
+                         "per launch, separate --pmc passes, gfx950 FETCH_SIZE x2 correction (MI355X_MICROARCH.md HBM section)" % dst},
+              open("profiles/pmc_traffic.json", "w"), indent=1, sort_keys=True)
 for k in sorted(stats, key=lambda k: -stats[k])[:8]:
     t = traffic.get(k, {})
     print("%-45s %9.1f us  fetch(x2) %8.1f MB  write %8.1f MB" % (k[:45], stats[k] / 1e3, t.get("fetch_bytes_x2", 0) / 1e6, t.get("write_bytes", 0) / 1e6))
