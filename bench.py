@@ -137,7 +137,7 @@ def main():
         dom = max(range(1 if partitioned else 0, 4), key=lambda i: avgs[i])
         kernel_avg_ms, klaunch = avgs[dom], ktimes[dom][1]
         # names as rocprofv3 prints them: k_partition<0> = FASTQ source (level 1), k_partition<1> = item source
-        knames = ("fastq_prepare(k_rec_blocks_sum+k_scan_u32+k_rec_blocks_apply+k_pack_planes)" if partitioned and world == 1
+        knames = ("segments(k_rec_segs_sum+k_scan_u32+k_rec_segs_apply)" if partitioned and world == 1
                   else "k_build_direct" if world == 1 else "k_insert_items", "k_partition<0>" if world == 1 else "k_partition<1> (level 1)",
                   "k_partition<1>" if world == 1 else "k_partition<1> (level 2)", "k_window_count")  # the counting form at this geometry
         per_launch = st["instances"]                # this rank's insertions per launch of the dominant kernel
