@@ -146,6 +146,13 @@ int qh_build_write_shard(qh_build* h, const char* path, int argc, const char* co
  * equalise shard sizes before qh_build_write_shard). */
 int qh_build_grow_to(qh_build* h, int lsize);
 
+/* Page-locked host memory for chunk buffers: the host-to-device copy of qh_build_add_fastq /
+ * qh_build_add_fastq_host_parsed from such a buffer is a direct DMA (pageable memory goes
+ * through a bounce buffer at a fifth of the rate). No counterpart in the reference (its reads
+ * stay on the host); used by the quorum_create_database tool. */
+int qh_host_alloc(void** out, size_t bytes);
+void qh_host_free(void* p);
+
 /* Number of leading bytes of a FASTQ buffer that form whole groups of 4 lines:
  * where the CLI cuts a stream into chunks for the GPU fast path. */
 size_t qh_fastq_4line_prefix(const char* buf, size_t len, int final_chunk);

@@ -15,6 +15,11 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <chrono>
+#include <thread>
+#include <unistd.h>
+#include <fcntl.h>
+#include <sys/stat.h>
 
 #include "../../include/quorum_hip.h"
 
@@ -145,49 +150,117 @@ static void parse(int argc, char** argv, args_t& a) {
   exit(rc == QH_EFULL ? 134 : EXIT_FAILURE);
 }
 
+// Chunk buffer in page-locked memory (plain malloc when pinning fails)
+struct chunk_buf {
+  char* p = nullptr;
+  size_t cap = 0;
+  bool pinned = false;
+  void reserve(size_t n) {
+    if (n <= cap) return;
+    char* np = nullptr;
+    bool npinned = qh_host_alloc((void**)&np, n) == QH_OK;
+    if (!npinned) np = (char*)malloc(n);
+    if (!np) { fprintf(stderr, "out of memory for a %zu-byte chunk\n", n); exit(EXIT_FAILURE); }
+    if (p) memcpy(np, p, cap);
+    release();
+    p = np; cap = n; pinned = npinned;
+  }
+  void release() {
+    if (!p) return;
+    if (pinned) qh_host_free(p); else free(p);
+    p = nullptr; cap = 0;
+  }
+  ~chunk_buf() { release(); }
+};
+
+// Fills dst[0, n) from the file: a regular file is read by a few threads at once (pread of
+// disjoint slices: the page-cache copy is what bounds the tool), anything else sequentially.
+static size_t read_some(int fd, bool regular, off_t* pos, char* dst, size_t n) {
+  if (!regular) {
+    size_t got = 0;
+    while (got < n) {
+      ssize_t r = read(fd, dst + got, n - got);
+      if (r < 0) { if (errno == EINTR) continue; perror("read"); exit(EXIT_FAILURE); }
+      if (r == 0) break;
+      got += (size_t)r;
+    }
+    return got;
+  }
+  struct stat st;
+  if (fstat(fd, &st) != 0) { perror("fstat"); exit(EXIT_FAILURE); }
+  const size_t left = st.st_size > *pos ? (size_t)(st.st_size - *pos) : 0;
+  if (n > left) n = left;
+  const size_t min_slice = (size_t)8 << 20;
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt > 8) nt = 8;
+  if (nt < 1 || n < 2 * min_slice) nt = 1;
+  const size_t slice = (n + nt - 1) / nt;
+  bool failed = false;
+  auto work = [&](size_t from, size_t to) {
+    while (from < to) {
+      ssize_t r = pread(fd, dst + from, to - from, *pos + (off_t)from);
+      if (r < 0) { if (errno == EINTR) continue; failed = true; return; }
+      if (r == 0) { failed = true; return; }  // file shrank under us
+      from += (size_t)r;
+    }
+  };
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, (size_t)t * slice, ((size_t)t + 1) * slice < n ? ((size_t)t + 1) * slice : n);
+  work(0, slice < n ? slice : n);
+  for (auto& t : th) t.join();
+  if (failed) { fprintf(stderr, "read error\n"); exit(EXIT_FAILURE); }
+  *pos += (off_t)n;
+  return n;
+}
+
 // Feeds one read file. Fast path: cut the stream into chunks of whole 4-line
 // groups and let the GPU index + validate them; the first chunk the GPU rejects
 // switches the rest of the file to the sequential host parser (Jellyfish rules).
 static void feed_file(qh_build* h, const char* path, size_t chunk_bytes) {
-  FILE* f = !strcmp(path, "-") ? stdin : fopen(path, "rb");
-  if (!f) { fprintf(stderr, "Can't open file '%s'\n", path); exit(EXIT_FAILURE); }
-  std::vector<char> buf(chunk_bytes);
+  const int fd = !strcmp(path, "-") ? 0 : open(path, O_RDONLY);
+  if (fd < 0) { fprintf(stderr, "Can't open file '%s'\n", path); exit(EXIT_FAILURE); }
+  struct stat st;
+  const bool regular = fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
+  if (regular && (size_t)st.st_size + 16 < chunk_bytes) chunk_bytes = (size_t)st.st_size + 16;
+  off_t pos = 0;
+  chunk_buf buf;
+  buf.reserve(chunk_bytes);
   size_t have = 0;
   bool fast = true, eof = false, any = false;
   while (!eof || have) {
-    while (!eof && have < buf.size()) {
-      size_t r = fread(buf.data() + have, 1, buf.size() - have, f);
-      if (r == 0) { eof = true; break; }
+    if (!eof && have < buf.cap) {
+      const size_t want = buf.cap - have, r = read_some(fd, regular, &pos, buf.p + have, want);
       have += r;
+      if (r < want) eof = true;
     }
     if (have == 0) break;
-    if (!any && buf[0] != '@' ) {
+    if (!any && buf.p[0] != '@' ) {
       fprintf(stderr, "Unsupported format in file '%s' (create_database needs FASTQ: it reads a quality for every base)\n", path);
       exit(EXIT_FAILURE);
     }
     any = true;
     size_t used = 0;
     if (fast) {
-      used = qh_fastq_4line_prefix(buf.data(), have, eof);
-      int rc = used ? qh_build_add_fastq(h, buf.data(), used) : QH_OK;
+      used = qh_fastq_4line_prefix(buf.p, have, eof);
+      int rc = used ? qh_build_add_fastq(h, buf.p, used) : QH_OK;
       if (rc == QH_OK && used) rc = qh_build_sync(h);
-      if (rc == QH_EFORMAT || (used == 0 && (eof || have == buf.size()))) { fast = false; used = 0; }
+      if (rc == QH_EFORMAT || (used == 0 && (eof || have == buf.cap))) { fast = false; used = 0; }
       else if (rc != QH_OK) die("create_database", rc);
     }
     if (!fast) {
-      int rc = qh_build_add_fastq_host_parsed(h, buf.data(), have, eof, &used);
+      int rc = qh_build_add_fastq_host_parsed(h, buf.p, have, eof, &used);
       if (rc == QH_OK) rc = qh_build_sync(h);
       if (rc != QH_OK) die("create_database", rc);
-      if (used == 0 && !eof && have == buf.size()) buf.resize(buf.size() * 2);  // a record longer than the chunk
+      if (used == 0 && !eof && have == buf.cap) buf.reserve(buf.cap * 2);  // a record longer than the chunk
     }
-    memmove(buf.data(), buf.data() + used, have - used);
+    memmove(buf.p, buf.p + used, have - used);
     have -= used;
     if (eof && used == 0 && have) {  // cannot happen: final chunks parse completely or fail
       fprintf(stderr, "Truncated fastq file '%s'\n", path);
       exit(EXIT_FAILURE);
     }
   }
-  if (f != stdin) fclose(f);
+  if (fd != 0) close(fd);
 }
 
 int main(int argc, char* argv[]) {
@@ -206,17 +279,23 @@ int main(int argc, char* argv[]) {
   if (!out) error(std::string("Failed to open output file '") + args.output + "'.");
   fclose(out);
 
+  const auto t_start = std::chrono::steady_clock::now();
+  auto secs = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
   qh_build* h = nullptr;
   int rc = qh_build_create(&h, (int)args.mer, (int)args.bits, args.size, (int)qual_thresh, args.reprobe, args.gpu, 0, 0);
   if (rc != QH_OK) error(qh_last_error());
 
   const char* cb = getenv("QUORUM_HIP_CHUNK_MB");
   size_t chunk = (cb && atol(cb) > 0 ? (size_t)atol(cb) : 256) << 20;
+  const double t_init = secs();
   for (const char* path : args.reads) feed_file(h, path, chunk);
 
   qh_build_stats st;
   if ((rc = qh_build_finish(h, &st)) != QH_OK) die("create_database", rc);
+  const double t_feed = secs();
   if ((rc = qh_build_write(h, args.output, argc, argv)) != QH_OK) die("create_database", rc);
+  if (getenv("QUORUM_HIP_VERBOSE"))
+    fprintf(stderr, "seconds: device+table %.3f  read+build %.3f  write %.3f\n", t_init, t_feed - t_init, secs() - t_feed);
   if (getenv("QUORUM_HIP_VERBOSE"))
     fprintf(stderr, "reads %llu  k-mers %llu  high-quality %llu  distinct %llu  slots %llu  doublings %llu\n",
             (unsigned long long)st.records, (unsigned long long)st.instances, (unsigned long long)st.hq_instances,

@@ -868,26 +868,48 @@ extern "C" int qh_build_write_shard(qh_build* h, const char* path, int argc, con
   }
   const uint64_t slots = 1ull << h->g.lsize;
   const uint64_t first = (uint64_t)h->g.shard_id * slots;
-  const size_t piece = (size_t)1 << 23;  // slots per staging piece (64 MiB)
-  std::vector<uint64_t> stage(slots < piece ? slots : piece);
   const int vbits = h->g.vbits;
   const uint64_t vpw = 64 / vbits;
   const uint64_t w0 = first / vpw, w1 = (first + slots + vpw - 1) / vpw;  // value words touched by this shard
-  std::vector<uint64_t> vimg(w1 - w0, 0);
-  for (uint64_t at = 0; ok && at < slots; at += stage.size()) {
-    const uint64_t n = slots - at < stage.size() ? slots - at : stage.size();
-    hipError_t e = hipMemcpyAsync(stage.data(), h->table + at, n * 8, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (e != hipSuccess) { close(fd); return qh_fail(QH_EHIP, "reading the table back failed: %s", hipGetErrorString(e)); }
-    ok = write_all(fd, stage.data(), n * 8, (off_t)(fh.offset + (first + at) * 8)) == 0;
-    const uint64_t vmask = h->g.vmask;
-    for (uint64_t i = 0; i < n; ++i) {
-      const uint64_t v = stage[i] & vmask;
-      if (!v) continue;
-      const uint64_t gi = first + at + i;
-      vimg[gi / vpw - w0] |= v << ((gi % vpw) * vbits);
-    }
+  // values image packed on the GPU while the keys image is on its way out
+  uint64_t* d_vimg = nullptr;
+  if (hipMalloc((void**)&d_vimg, (w1 - w0) * 8) != hipSuccess) {
+    (void)hipGetLastError();
+    close(fd);
+    return qh_fail(QH_ENOMEM, "cannot allocate the %llu-byte values image", (unsigned long long)((w1 - w0) * 8));
   }
+  qh_launch_vals_image(h->table, h->g, first, slots, w0, w1 - w0, d_vimg, h->stream);
+  // keys image: two pinned staging pieces, the copy of piece i+1 overlaps the pwrite of piece i
+  const size_t piece = slots < ((size_t)1 << 22) ? (size_t)slots : ((size_t)1 << 22);  // slots per piece (32 MiB)
+  uint64_t* stage[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+    e = hipHostMalloc((void**)&stage[i], piece * 8, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+  }
+  auto issue = [&](uint64_t at, int b) -> hipError_t {
+    const uint64_t n = slots - at < piece ? slots - at : piece;
+    hipError_t r = hipMemcpyAsync(stage[b], h->table + at, n * 8, hipMemcpyDeviceToHost, h->stream);
+    return r == hipSuccess ? hipEventRecord(ev[b], h->stream) : r;
+  };
+  if (e == hipSuccess) e = issue(0, 0);
+  int b = 0;
+  for (uint64_t at = 0; ok && e == hipSuccess && at < slots; at += piece, b ^= 1) {
+    const uint64_t n = slots - at < piece ? slots - at : piece;
+    if (at + piece < slots) e = issue(at + piece, b ^ 1);
+    if (e == hipSuccess) e = hipEventSynchronize(ev[b]);
+    if (e == hipSuccess) ok = write_all(fd, stage[b], n * 8, (off_t)(fh.offset + (first + at) * 8)) == 0;
+  }
+  std::vector<uint64_t> vimg(w1 - w0, 0);
+  if (e == hipSuccess) e = hipMemcpyAsync(vimg.data(), d_vimg, (w1 - w0) * 8, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  for (int i = 0; i < 2; ++i) {
+    if (stage[i]) { hipError_t x = hipHostFree(stage[i]); (void)x; }
+    if (ev[i]) { hipError_t x = hipEventDestroy(ev[i]); (void)x; }
+  }
+  { hipError_t x = hipFree(d_vimg); (void)x; }
+  if (e != hipSuccess) { close(fd); return qh_fail(QH_EHIP, "reading the table back failed: %s", hipGetErrorString(e)); }
   if (ok) {
     const off_t voff = (off_t)(fh.offset + fh.key_bytes + w0 * 8);
     if (h->g.shard_bits && (first % vpw || (first + slots) % vpw)) {
@@ -918,6 +940,18 @@ extern "C" int qh_build_as_query(qh_build* h, qh_query** out) {
   if (rc) return rc;
   if (h->g.shard_bits) return qh_fail(QH_EBADARG, "a sharded build handle cannot serve lookups on its own");
   return qh_query_from_table(h->device, h->table, h->g, out);
+}
+
+extern "C" int qh_host_alloc(void** out, size_t bytes) {
+  if (!out || !bytes) return qh_fail(QH_EBADARG, "null argument");
+  *out = nullptr;
+  hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) { (void)hipGetLastError(); return qh_fail(QH_ENOMEM, "cannot pin %zu bytes of host memory: %s", bytes, hipGetErrorString(e)); }
+  return QH_OK;
+}
+
+extern "C" void qh_host_free(void* p) {
+  if (p) { hipError_t e = hipHostFree(p); (void)e; }
 }
 
 // number of leading bytes of buf that form whole groups of 4 lines (the chunk cut

@@ -111,6 +111,10 @@ void qh_launch_histo(const uint64_t* table, const qh_geom& g, unsigned long long
 void qh_launch_dump(const uint64_t* table, const qh_geom& g, uint64_t* mers, uint64_t* vals,
                     uint64_t cap, qh_meta* meta, hipStream_t s);
 
+// values image words [w0, w0 + nwords) of the database file for this shard's slots
+void qh_launch_vals_image(const uint64_t* table, const qh_geom& g, uint64_t first, uint64_t slots, uint64_t w0,
+                          uint64_t nwords, uint64_t* out, hipStream_t s);
+
 // --- roofline microbenchmarks -------------------------------------------------------
 void qh_launch_random_access(uint64_t* table, int lsize, uint64_t n, int mode, uint64_t seed,
                              unsigned long long* sink, hipStream_t s);

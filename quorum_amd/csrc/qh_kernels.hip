@@ -492,6 +492,31 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
   return z ^ (z >> 31);
 }
 
+// The values image of the database file (atomic_bits_array layout: 64 / vbits value fields per
+// 64-bit word, none straddling a word; mer_database.hpp:115-126 writes vals_ raw): word wi of the
+// whole-file image for this shard's slots [first, first + slots).
+__global__ __launch_bounds__(QH_BLOCK) void k_vals_image(const uint64_t* __restrict__ table, const qh_geom g,
+                                                         uint64_t first, uint64_t slots, uint64_t w0, uint64_t nwords,
+                                                         uint64_t* __restrict__ out) {
+  const uint32_t vpw = 64u / (uint32_t)g.vbits;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t base = (w0 + i) * vpw;
+    uint64_t word = 0;
+    for (uint32_t j = 0; j < vpw; ++j) {
+      const uint64_t gi = base + j;
+      if (gi >= first && gi - first < slots) word |= (table[gi - first] & g.vmask) << (j * g.vbits);
+    }
+    out[i] = word;
+  }
+}
+
+void qh_launch_vals_image(const uint64_t* table, const qh_geom& g, uint64_t first, uint64_t slots, uint64_t w0,
+                          uint64_t nwords, uint64_t* out, hipStream_t s) {
+  if (!nwords) return;
+  hipLaunchKernelGGL(k_vals_image, dim3(grid_for(nwords, QH_BLOCK, 16384)), dim3(QH_BLOCK), 0, s, table, g, first, slots,
+                     w0, nwords, out);
+}
+
 // mode 0: one 64-bit atomicCAS per update at a uniformly random slot
 // mode 1: one 8-byte load per update
 // mode 2: relaxed load followed by a dependent CAS (the insert path's shape)

@@ -1,0 +1,24 @@
+"""End-to-end timing of the quorum_create_database tool on the bench FASTQ (file in page cache):
+wall clock of the whole command, and the k-mers/s that makes. Run on the GPU box."""
+import json, os, subprocess, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from quorum_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+cli = os.path.join(ROOT, "quorum_amd", "bin", "quorum_create_database")
+path = "/tmp/cli_bench.fastq"
+g = synth.make_genome(5_000_000)
+fq = synth.make_fastq(g, 2_000_000, 100)
+fq.tofile(path)
+out = "/tmp/cli_bench.db"
+res = []
+for it in range(3):
+    t0 = time.time()
+    r = subprocess.run([cli, "-s", "50M", "-m", "24", "-b", "7", "-q", "38", "-o", out, path],
+                       capture_output=True, text=True, env=dict(os.environ, QUORUM_HIP_VERBOSE="1"))
+    dt = time.time() - t0
+    assert r.returncode == 0, r.stderr
+    res.append(dt)
+kmers = int(r.stderr.split("k-mers")[1].split()[0])
+print(json.dumps({"fastq_bytes": int(fq.size), "kmers": kmers, "wall_s": res, "best_kmers_per_s": kmers / min(res),
+                  "db_bytes": os.path.getsize(out), "stderr": r.stderr.strip()}))
