@@ -43,6 +43,7 @@
 
 #define RB_TILE 1024  // records per scan tile
 #define QP_SEG 12     // k-mers per segment (= items a lane keeps in registers per tile)
+static_assert(QP_SEG == QH_SEG_KMERS && QP_SEG == QP_BLOCKS_PER_WAVE, "segment size is shared with the host-side buffer sizing");
 
 __device__ __forceinline__ uint32_t rec_nsegs(uint32_t len, uint32_t k) {
   return len >= k ? (len - k + 1 + QP_SEG - 1) / QP_SEG : 0;

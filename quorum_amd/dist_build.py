@@ -103,6 +103,31 @@ def exchange_items(send, send_counts, group=None):
     return recv, recv_counts
 
 
+_LIST_ALL_TO_ALL_OK = True
+
+
+def exchange_buckets(buckets, counts, group=None):
+    """The same exchange straight from the per-destination bucket rows (2-D int64 CUDA tensor,
+    counts[s] items of row s are for rank s): with RCCL the rows are sent where they lie
+    (dist.all_to_all over views), which saves packing 8 bytes per item into one send buffer; any
+    other backend, or a torch build that refuses the list form, takes exchange_items."""
+    global _LIST_ALL_TO_ALL_OK
+    world = dist.get_world_size(group)
+    if _LIST_ALL_TO_ALL_OK and buckets.device.type == "cuda" and dist.get_backend(group) == "nccl":
+        try:
+            sc = torch.tensor(counts, dtype=torch.int64, device=buckets.device)
+            rc = torch.empty(world, dtype=torch.int64, device=buckets.device)
+            dist.all_to_all_single(rc, sc, group=group)
+            recv_counts = rc.tolist()
+            recv = torch.empty(int(sum(recv_counts)), dtype=torch.int64, device=buckets.device)
+            dist.all_to_all(list(recv.split(recv_counts)), [buckets[s, :counts[s]] for s in range(world)], group=group)
+            return recv, recv_counts
+        except (RuntimeError, NotImplementedError):
+            _LIST_ALL_TO_ALL_OK = False  # every rank fails alike (same torch build): fall back together
+    send = torch.cat([buckets[s, :counts[s]] for s in range(world)])
+    return exchange_items(send, counts, group)
+
+
 class ShardedBuilder:
     """Per-rank driver: extract+bucket the local chunk, exchange, insert what this shard owns."""
 
@@ -137,8 +162,7 @@ class ShardedBuilder:
                                                       C.c_void_p(self._buckets.data_ptr()), self._buckets.shape[1],
                                                       C.c_void_p(self._counts.data_ptr())))
         counts = self._counts.tolist()
-        send = torch.cat([self._buckets[s, :counts[s]] for s in range(self.world)])
-        recv, _ = exchange_items(send, counts, self.group)
+        recv, _ = exchange_buckets(self._buckets, counts, self.group)
         if recv.numel():
             self.h.add_hashed_device(recv.data_ptr(), recv.numel())
             self.h.sync()  # recv must stay alive until the insert kernel has consumed it
