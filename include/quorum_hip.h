@@ -146,6 +146,14 @@ int qh_build_write_shard(qh_build* h, const char* path, int argc, const char* co
  * equalise shard sizes before qh_build_write_shard). */
 int qh_build_grow_to(qh_build* h, int lsize);
 
+/* The quorum driver's quality-offset detection (src/quorum.in:129-152): the smallest quality
+ * character of the first 1000 records (header lines 1..4000) of a FASTQ buffer, minus 2 when it is
+ * 35 or 66 (Illumina files without qualities 0 and 1). *min_q_char receives it; QH_EFORMAT with
+ * "Found an unusual minimum quality char ..." unless it is 33, 59 or 64, or "Invalid fastq format"
+ * when a record stops before its quality line. The driver then runs
+ * quorum_create_database -q min_q_char + min_quality (:155-156). Host-only. */
+int qh_detect_min_qual_char(const char* buf, size_t len, int* min_q_char);
+
 /* Page-locked host memory for chunk buffers: the host-to-device copy of qh_build_add_fastq /
  * qh_build_add_fastq_host_parsed from such a buffer is a direct DMA (pageable memory goes
  * through a bounce buffer at a fifth of the rate). No counterpart in the reference (its reads

@@ -942,6 +942,38 @@ extern "C" int qh_build_as_query(qh_build* h, qh_query** out) {
   return qh_query_from_table(h->device, h->table, h->g, out);
 }
 
+extern "C" int qh_detect_min_qual_char(const char* buf, size_t len, int* min_q_char) {
+  if (!buf || !min_q_char) return qh_fail(QH_EBADARG, "null argument");
+  int minq = 256;
+  size_t p = 0, line = 0;
+  auto next_line = [&](size_t* b, size_t* e) -> bool {  // perl's <$io>: false at end of input
+    if (p >= len) return false;
+    const void* nl = memchr(buf + p, '\n', len - p);
+    *b = p;
+    *e = nl ? (size_t)((const char*)nl - buf) : len;
+    p = nl ? *e + 1 : len;
+    ++line;
+    return true;
+  };
+  size_t b, e;
+  while (next_line(&b, &e)) {            // header
+    if (line > 4000) break;
+    next_line(&b, &e);                   // sequence
+    next_line(&b, &e);                   // quality header
+    if (!next_line(&b, &e)) return qh_fail(QH_EFORMAT, "Invalid fastq format");
+    for (size_t i = b; i < e; ++i) {
+      const int c = (unsigned char)buf[i];
+      if (c < minq) minq = c;
+    }
+  }
+  if (minq == 35 || minq == 66) minq -= 2;  // special Illumina case where quality 0 and 1 do not appear
+  *min_q_char = minq;
+  if (minq != 33 && minq != 59 && minq != 64)
+    return qh_fail(QH_EFORMAT, "Found an unusual minimum quality char of %d (%c). Stopping now. Use option -m to override",
+                   minq, minq >= 32 && minq < 127 ? minq : '?');
+  return QH_OK;
+}
+
 extern "C" int qh_host_alloc(void** out, size_t bytes) {
   if (!out || !bytes) return qh_fail(QH_EBADARG, "null argument");
   *out = nullptr;

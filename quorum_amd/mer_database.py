@@ -173,6 +173,15 @@ class HashWithQuality:
             pass
 
 
+def detect_min_qual_char(data):
+    """the quorum driver's quality-offset detection over the first 1000 records (quorum.in:129-152);
+    raises QhError for an unusual minimum like the driver stops"""
+    data = bytes(data)
+    c = C.c_int()
+    check(lib.qh_detect_min_qual_char(data, len(data), C.byref(c)))
+    return c.value
+
+
 def poisson_term(lam, i):
     """double poisson_term(double lambda, unsigned int i) (error_correct_reads.cc:53-61)"""
     return lib.qh_poisson_term(lam, i)

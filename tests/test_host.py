@@ -133,3 +133,23 @@ def test_cli_help_lists_reference_switches():
     assert r.returncode == 0
     for sw in ("--size", "--mer", "--bits", "--min-qual-value", "--min-qual-char", "--threads", "--output", "--reprobe"):
         assert sw in r.stdout
+
+
+def test_detect_min_qual_char_like_the_driver():
+    """src/quorum.in:129-152 restated by hand: min over the quality lines of the first 1000 records,
+    35 -> 33 and 66 -> 64, anything but 33 / 59 / 64 stops the run"""
+    def fq(quals):
+        return "".join("@r%d\nACGT\n+\n%s\n" % (i, q) for i, q in enumerate(quals)).encode()
+    assert quorum_amd.detect_min_qual_char(fq(["IIII", "I#II", "!III"])) == 33
+    assert quorum_amd.detect_min_qual_char(fq(["IIII", "I#II"])) == 33       # 35 - 2
+    assert quorum_amd.detect_min_qual_char(fq(["hhhh", "hBhh"])) == 64       # 66 - 2
+    assert quorum_amd.detect_min_qual_char(fq(["hhhh", "h@hh"])) == 64
+    assert quorum_amd.detect_min_qual_char(fq(["hhhh", "h;hh"])) == 59
+    with pytest.raises(quorum_amd.QhError, match="unusual minimum quality char of 40"):
+        quorum_amd.detect_min_qual_char(fq(["IIII", "I(II"]))
+    # only the first 1000 records count: a '!' in record 1001 is not seen
+    with pytest.raises(quorum_amd.QhError, match="unusual minimum quality char of 104"):
+        quorum_amd.detect_min_qual_char(fq(["hhhh"] * 1000 + ["!hhh"]))
+    assert quorum_amd.detect_min_qual_char(fq(["hhhh"] * 999 + ["@hhh"] + ["!hhh"])) == 64
+    with pytest.raises(quorum_amd.QhError, match="Invalid fastq format"):
+        quorum_amd.detect_min_qual_char(b"@r0\nACGT\n+\n")
