@@ -272,6 +272,73 @@ int qh_query_histo(qh_query* q, uint64_t* histo /* [1001][2] */);
  * bulk export of (mer, value) pairs. */
 int qh_query_dump(qh_query* q, uint64_t* mers, uint64_t* vals, uint64_t cap, uint64_t* n);
 
+/* ------------------------------------------------------ read corrector */
+
+/* The switches of quorum_error_correct_reads (src/error_correct_reads_cmdline.yaggo:6-71)
+ * as main() hands them to error_correct_t (src/error_correct_reads.cc:720-736). */
+typedef struct qh_correct_params {
+  int32_t skip;             /* -s  bases to skip for the start k-mer            (1) */
+  int32_t good;             /* -g  good k-mers in a row for an anchor           (2) */
+  int32_t anchor;           /* -a  minimum count of an anchor k-mer             (3) */
+  int32_t min_count;        /* -m  minimum count of a "good" k-mer              (1) */
+  int32_t cutoff;           /* -p  Poisson cutoff (qh_query_poisson_cutoff when not given, :712-718) */
+  int32_t window;           /* -w  window size, 0 = k   (error_correct_reads.cc:206; yaggo default 10) */
+  int32_t error;            /* -e  errors allowed in a window, 0 = k/2 (:207; yaggo default 3)        */
+  int32_t qual_cutoff;      /* -q/-Q compared as a char; 127 when neither is given (:684-685)          */
+  int32_t trim_contaminant; /* --trim-contaminant                                                      */
+  int32_t do_homo_trim;     /* --homo-trim given                                                       */
+  int32_t homo_trim;        /* its value                                                               */
+  int32_t no_discard;       /* -d  output a single N for a discarded read                              */
+  double collision_prob;    /* apriori_error_rate / 3 (:734)                                           */
+  double poisson_threshold; /* --poisson-threshold (:735)                                              */
+} qh_correct_params;
+
+typedef struct qh_correct_stats {
+  uint64_t reads;          /* records seen                                 */
+  uint64_t corrected;      /* reads written to the .fa stream with a sequence */
+  uint64_t skipped;        /* "Skipped <header>: <reason>" lines           */
+  uint64_t substitutions;  /* pos:sub:X-Y entries                          */
+  uint64_t truncations;    /* pos:3_trunc + pos:5_trunc entries            */
+  uint64_t bases_in;       /* sequence bytes of the chunk                  */
+  uint64_t bases_out;      /* sequence bytes written                       */
+} qh_correct_stats;
+
+typedef struct qh_corrector qh_corrector; /* ~ error_correct_t + its error_correct_instance workers */
+
+/* error_correct_t set up as in main (src/error_correct_reads.cc:720-736) over an open
+ * database and an optional contaminant set (NULL = contaminant_no_database, :75-81; same k
+ * and device as db, :703-705). Both handles must outlive the corrector. */
+int qh_corrector_create(qh_corrector** out, qh_query* db, qh_query* contaminant, const qh_correct_params* p);
+void qh_corrector_destroy(qh_corrector* c);
+
+/* error_correct_instance::start (src/error_correct_reads.cc:246-341) over one chunk of FASTQ
+ * text resident in HBM (16-byte aligned, strict 4-line records, whole records only): the
+ * record index, find_starting_mer (:609-643), extend in both directions (:386-565), homo_trim
+ * (:567-597) and the text of both output streams are made on the GPU; the call only enqueues
+ * kernels on the corrector's stream (or `hip_stream` when not NULL). One read per lane; reads
+ * keep their input order in the output (upstream with -t 1). QH_EFORMAT is deferred to
+ * qh_corrector_fetch, like qh_build_add_fastq_device defers it to qh_build_sync. */
+int qh_corrector_correct_device(qh_corrector* c, const void* dev_buf, size_t len, void* hip_stream);
+
+/* Waits for the chunk and hands out its two text streams: `fa` is what upstream writes to
+ * <prefix>.fa (">header fwd_log bwd_log\nSEQUENCE\n", :334-336; ">header\nN\n" for a discarded
+ * read under -d, :274-275), `log` what it writes to <prefix>.log ("Skipped header: reason\n",
+ * :272). The pointers are library-owned pinned host memory, valid until the next call on this
+ * corrector. stats may be NULL. */
+int qh_corrector_fetch(qh_corrector* c, const char** fa, size_t* fa_len, const char** log, size_t* log_len,
+                       qh_correct_stats* stats);
+
+/* Host-buffer form: copies the chunk to the device and corrects it. The GPU path takes the
+ * leading whole 4-line groups; a chunk the GPU indexer rejects is parsed by the sequential
+ * host parser with Jellyfish's FASTQ rules (multi-line records) and corrected by the same
+ * kernel. *consumed receives the bytes that formed complete records when final_chunk is 0.
+ * Results are collected with qh_corrector_fetch. */
+int qh_corrector_correct_fastq(qh_corrector* c, const char* buf, size_t len, int final_chunk, size_t* consumed);
+
+/* HIP-event time of the correction kernel (k_correct_reads) and of the whole enqueued chunk
+ * (index + correct + format) of the last qh_corrector_correct_* call, in milliseconds. */
+int qh_corrector_kernel_time(qh_corrector* c, double* correct_ms, double* chunk_ms);
+
 /* -------------------------------------------------- measurement support */
 
 /* HIP-event timing of the main kernels of each chunk, recorded on the stream the

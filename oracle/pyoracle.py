@@ -70,6 +70,44 @@ _o.qo_db_poisson_cutoff.argtypes = [C.c_void_p, C.c_double, C.c_double]
 _o.qo_db_add_fasta.restype = C.c_int64
 _o.qo_db_add_fasta.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
 
+
+
+class QoEcParams(C.Structure):
+    """qo_ec_params of oracle/error_correct_oracle.c (switches of error_correct_reads_cmdline.yaggo)"""
+    _fields_ = [("skip", C.c_int), ("good", C.c_int), ("anchor", C.c_int), ("min_count", C.c_int), ("cutoff", C.c_int),
+                ("window", C.c_int), ("error", C.c_int), ("qual_cutoff", C.c_int), ("trim_contaminant", C.c_int),
+                ("do_homo_trim", C.c_int), ("homo_trim", C.c_int), ("no_discard", C.c_int),
+                ("collision_prob", C.c_double), ("poisson_threshold", C.c_double)]
+
+
+def ec_params(cutoff, skip=1, good=2, anchor=3, min_count=1, window=10, error=3, qual_cutoff=127,
+              trim_contaminant=False, homo_trim=None, no_discard=False, apriori_error_rate=0.01,
+              poisson_threshold=1e-6):
+    """defaults of error_correct_reads_cmdline.yaggo:9-62 and error_correct_reads.cc:684-685,734-735"""
+    return QoEcParams(skip, good, anchor, min_count, cutoff, window, error, qual_cutoff, int(trim_contaminant),
+                      int(homo_trim is not None), 0 if homo_trim is None else homo_trim, int(no_discard),
+                      apriori_error_rate / 3, poisson_threshold)
+
+
+_o.qo_ec_correct_fastq.restype = C.c_int64
+_o.qo_ec_correct_fastq.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(QoEcParams), C.c_char_p, C.c_size_t,
+                                   C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                   C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+_o.qo_ec_print_log.restype = C.c_size_t
+_o.qo_ec_print_log.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_size_t, C.c_char_p]
+
+
+def ec_print_log(direction, entries):
+    """err_log's operator<< (err_log.hpp:111-135); entries = [(type, pos, from, to)], type 0 sub / 1 trunc"""
+    flat = []
+    for t, pos, f, to in entries:
+        flat += [t, pos, ord(f) if f else 0, ord(to) if to else 0]
+    arr = (C.c_int * max(1, len(flat)))(*flat)
+    out = C.create_string_buffer(32 * len(entries) + 16)
+    n = _o.qo_ec_print_log(direction, arr, len(entries), out)
+    return out.raw[:n]
+
+
 PARSE_ERRORS = {-1: "Truncated fastq file", -2: "Invalid fastq file: wrong number of quals",
                 -3: "Invalid fastq file: header missing", -4: "Unsupported format", -5: "out of capacity",
                 -10: "Hash is full"}
@@ -210,6 +248,18 @@ class OracleDB:
         h = np.zeros((1001, 2), dtype=np.uint64)
         _o.qo_db_histo(self._db, h.ctypes.data_as(_u64p))
         return h
+
+    def correct_fastq(self, data, params, contaminant=None):
+        """quorum_error_correct_reads (one thread) over a FASTQ buffer -> (fa bytes, log bytes, reads)"""
+        data = bytes(data)
+        cap = 3 * len(data) + 4096
+        fa, lg = C.create_string_buffer(cap), C.create_string_buffer(cap)
+        nfa, nlg = C.c_size_t(), C.c_size_t()
+        n = _o.qo_ec_correct_fastq(self._db, contaminant._db if contaminant is not None else None, C.byref(params),
+                                   data, len(data), fa, cap, C.byref(nfa), lg, cap, C.byref(nlg))
+        if n < 0:
+            raise ValueError(PARSE_ERRORS.get(n, str(n)))
+        return fa.raw[:nfa.value], lg.raw[:nlg.value], n
 
     def close(self):
         if self._db:

@@ -147,8 +147,8 @@ static size_t line_end(const char* buf, size_t len, size_t p) {
   return e ? (size_t)(e - buf) : len;
 }
 
-int64_t qo_parse_fastq(const char* buf, size_t len, qo_rec* recs, size_t cap,
-                       char* scratch, size_t scratch_cap) {
+int64_t qo_parse_fastq_hdr(const char* buf, size_t len, qo_rec* recs, size_t cap,
+                           char* scratch, size_t scratch_cap, uint64_t* hdr_off, uint32_t* hdr_len) {
   size_t p = 0, n = 0, sp = 0;
   if (len == 0) return 0;
   if (buf[0] != '@') return -4;
@@ -156,6 +156,7 @@ int64_t qo_parse_fastq(const char* buf, size_t len, qo_rec* recs, size_t cap,
     if (n >= cap) return -5;
     /* is.ignore(1); getline(header) */
     size_t e = line_end(buf, len, p + 1 <= len ? p + 1 : len);
+    if (hdr_off) { hdr_off[n] = p + 1 <= len ? p + 1 : len; hdr_len[n] = (uint32_t)(e - hdr_off[n]); }
     p = e < len ? e + 1 : len;
     /* sequence lines */
     size_t s0 = p, slen = 0, nlines = 0, first_len = 0;
@@ -221,6 +222,11 @@ int64_t qo_parse_fastq(const char* buf, size_t len, qo_rec* recs, size_t cap,
     }
   }
   return (int64_t)n;
+}
+
+int64_t qo_parse_fastq(const char* buf, size_t len, qo_rec* recs, size_t cap,
+                       char* scratch, size_t scratch_cap) {
+  return qo_parse_fastq_hdr(buf, len, recs, cap, scratch, scratch_cap, NULL, NULL);
 }
 
 /* ------------------------------------------------------- hash_with_quality */

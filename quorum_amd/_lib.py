@@ -31,6 +31,18 @@ class QhDbInfo(C.Structure):
                 ("shard_bits", C.c_uint32), ("window_bits", C.c_uint32), ("format", C.c_char * 32)]
 
 
+class QhCorrectParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("skip", "good", "anchor", "min_count", "cutoff", "window", "error", "qual_cutoff",
+                 "trim_contaminant", "do_homo_trim", "homo_trim", "no_discard")] + \
+               [("collision_prob", C.c_double), ("poisson_threshold", C.c_double)]
+
+
+class QhCorrectStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("reads", "corrected", "skipped", "substitutions", "truncations", "bases_in", "bases_out")]
+
+
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         "quorum_amd: %s is missing. Build it with `make -C quorum_amd/csrc` "
@@ -86,6 +98,13 @@ SIGNATURES = [
     ("qh_query_batch_contaminant", C.c_int, [_p, _p, _u64p, C.c_size_t, _u64p, _u8p]),
     ("qh_query_batch_contaminant_device", C.c_int, [_p, _p, _p, C.c_size_t, _p, _p, _p]),
     ("qh_query_dump", C.c_int, [_p, _u64p, _u64p, C.c_uint64, _u64p]),
+    ("qh_corrector_create", C.c_int, [C.POINTER(_p), _p, _p, C.POINTER(QhCorrectParams)]),
+    ("qh_corrector_destroy", None, [_p]),
+    ("qh_corrector_correct_device", C.c_int, [_p, _p, C.c_size_t, _p]),
+    ("qh_corrector_fetch", C.c_int, [_p, C.POINTER(_p), C.POINTER(C.c_size_t), C.POINTER(_p), C.POINTER(C.c_size_t),
+                                     C.POINTER(QhCorrectStats)]),
+    ("qh_corrector_correct_fastq", C.c_int, [_p, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_size_t)]),
+    ("qh_corrector_kernel_time", C.c_int, [_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("qh_build_enable_timing", C.c_int, [_p, C.c_int]),
     ("qh_build_kernel_time", C.c_int, [_p, C.c_int, C.POINTER(C.c_double), _u64p]),
     ("qh_build_set_mode", C.c_int, [_p, C.c_int, C.c_int]),

@@ -529,8 +529,8 @@ extern "C" int qh_build_add_records_device(qh_build* h, const void* dev_buf, siz
 // Sequential parser with jellyfish::whole_sequence_parser's FASTQ rules. Returns
 // QH_OK and the records of every COMPLETE record; *consumed = bytes they span.
 // Multi-line records are re-flowed into `scratch` (offsets relative to scratch_base).
-static int parse_fastq_host(const char* buf, size_t len, bool final_chunk, std::vector<qh_record>& recs,
-                            std::string& scratch, size_t* consumed) {
+int qh_parse_fastq_host(const char* buf, size_t len, bool final_chunk, std::vector<qh_record>& recs,
+                        std::string& scratch, size_t* consumed, std::vector<qh_hdr>* hdrs) {
   size_t p = 0;
   *consumed = 0;
   auto eol = [&](size_t from) -> size_t {
@@ -543,6 +543,7 @@ static int parse_fastq_host(const char* buf, size_t len, bool final_chunk, std::
                     : qh_fail(QH_EFORMAT, "Invalid fastq file: header missing");
     size_t e = eol(p);
     if (e >= len) { if (final_chunk) return qh_fail(QH_EFORMAT, "Truncated fastq file"); break; }
+    const qh_hdr hd = {(uint32_t)(p + 1), (uint32_t)(e - p - 1)};  // is.ignore(1); getline(header)
     size_t q = e + 1;
     // sequence lines up to the '+' line
     const size_t seq_first = q;
@@ -595,6 +596,7 @@ static int parse_fastq_host(const char* buf, size_t len, bool final_chunk, std::
     r.qual_off = (uint32_t)(qual_multi ? qspos : qual_first);
     r.reserved = (seq_multi ? 1u : 0u) | (qual_multi ? 2u : 0u);
     recs.push_back(r);
+    if (hdrs) hdrs->push_back(hd);
     p = q;
     *consumed = p;
   }
@@ -610,7 +612,7 @@ extern "C" int qh_build_add_fastq_host_parsed(qh_build* h, const char* buf, size
   std::vector<qh_record> recs;
   std::string scratch;
   size_t used = 0;
-  int rc = parse_fastq_host(buf, len, final_chunk != 0, recs, scratch, &used);
+  int rc = qh_parse_fastq_host(buf, len, final_chunk != 0, recs, scratch, &used, nullptr);
   if (rc) return rc;
   if (consumed) *consumed = used;
   if (recs.empty()) return QH_OK;

@@ -1,0 +1,1025 @@
+// qh_correct.hip -- Quorum's read corrector (quorum_error_correct_reads) on gfx950: SURVEY 8(f)-1.
+//
+// Replaces (paths relative to the Quorum tree):
+//   error_correct_instance::start       src/error_correct_reads.cc:246-341
+//   find_starting_mer                   src/error_correct_reads.cc:609-643
+//   extend, both directions             src/error_correct_reads.cc:386-565
+//   log_substitution, check_contaminant src/error_correct_reads.cc:346-379
+//   homo_trim                           src/error_correct_reads.cc:567-597
+//   err_log<T> + its printer            src/err_log.hpp:55-135
+//   forward/backward counters and logs  src/error_correct_reads.hpp:87-173
+//   kmer_t, forward_mer, backward_mer   src/kmer.hpp:11-106
+//   the two output streams              src/error_correct_reads.cc:272-275,334-336
+//
+// One read per lane. A read is a serial chain of dependent table lookups (4 per base, 16 more
+// where several alternatives survive), so the kernel is bound by the random 8-byte load rate
+// of HBM (measured 54 G/s, qh_bench_random_access mode 1) and wants as many reads in flight as
+// registers allow; nothing here is MFMA-shaped. Both directions of extend() run in ONE loop
+// with the direction as lane state (d = +1 / -1), so a lane that finishes its forward
+// extension early goes on backwards while its neighbours are still extending forwards.
+// The two counters of error_correct_reads.hpp become "directional coordinates" d * raw: every
+// forward_counter / backward_counter operator is then plain integer arithmetic (an `unsigned`
+// compared with a counter is converted to a counter first, so `pos > _window` of
+// err_log.hpp:89 is d*raw > d*window).
+// The error logs live in global memory (at most len + 4 entries per read, entry = one word).
+// The text of both output streams is produced on the device too (sizes -> scan -> write), in
+// input order, so the host only copies two byte strings out.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <math.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "qh_internal.h"
+#include "qh_device.h"
+
+#define EC_BLOCK 256
+#define EC_FMT_BLOCK 1024
+#define EC_RES_WORDS 8  // per read: status, start, end, nf, nb, offset of the backward log, fa_bytes, log_bytes
+
+enum { EC_ST_OK = 0, EC_ST_CONTAMINANT = 1, EC_ST_NO_START = 2, EC_ST_HOMOPOLYMER = 3 };
+enum { EC_OK = 0, EC_TRUNCATE = 1, EC_ERROR = 2 };
+
+struct qh_ec_dev {
+  qh_geom g;
+  const uint64_t* table;
+  qh_geom cg;
+  const uint64_t* ctable;  // null: contaminant_no_database
+  int skip, good, anchor, min_count, cutoff, window, error, qual_cutoff;
+  int trim_contaminant, do_homo_trim, homo_trim, no_discard;
+  // bit [c * ptab_stride + sum]: poisson_term(sum * collision_prob, c) < poisson_threshold, evaluated by the
+  // host's libm (error_correct_reads.cc:448-450); ptab_stride == 0: evaluate on the device
+  int ptab_stride;
+  const uint32_t* ptab;
+  double collision_prob, poisson_threshold;
+};
+
+struct qh_ec_totals {
+  unsigned long long fa_bytes, log_bytes;
+  unsigned long long fa_cap, log_cap;  // capacity the format kernel may write
+  unsigned long long reads, corrected, skipped, substitutions, truncations, bases_in, bases_out;
+  unsigned int overflow;               // a stream did not fit its buffer: nothing of it was written
+};
+
+// ------------------------------------------------------------------ lookups
+
+struct ec_slot4 { qh_pos p[4]; uint64_t s[4]; };
+
+// first probe of a lookup already loaded (s): finish database_query::operator[]
+__device__ __forceinline__ uint64_t ec_resolve(const qh_geom& g, const uint64_t* __restrict__ table, const qh_pos& p,
+                                               uint64_t s) {
+  if (p.shard != (uint32_t)g.shard_id) return 0;
+  const uint64_t wmask = qh_low_mask(g.wbits);
+  const uint64_t base = p.home & ~wmask;
+  for (uint32_t i = 0;;) {
+    if (s == 0) return 0;
+    if ((s >> g.vbits) == (p.tag0 | (i + 1))) return s & g.vmask;
+    if (++i > (uint32_t)g.max_reprobe) return 0;
+    s = table[base | ((p.home + i) & wmask)];
+  }
+}
+
+__device__ __forceinline__ uint64_t ec_lookup(const qh_geom& g, const uint64_t* __restrict__ table, uint64_t canon) {
+  const qh_pos p = qh_locate(g, canon);
+  return ec_resolve(g, table, p, table[p.home]);
+}
+
+// kmer_t (kmer.hpp:11-61) as two registers
+struct ec_mer { uint64_t f, r; };
+__device__ __forceinline__ uint64_t ec_canonical(const ec_mer& m) { return m.f < m.r ? m.f : m.r; }
+__device__ __forceinline__ void ec_shift_left(ec_mer& m, int k, uint64_t kmask, int x) {
+  m.f = ((m.f << 2) | (uint64_t)x) & kmask;
+  m.r = (m.r >> 2) | ((uint64_t)(3 - x) << (2 * (k - 1)));
+}
+__device__ __forceinline__ void ec_shift_right(ec_mer& m, int k, uint64_t kmask, int x) {
+  m.f = (m.f >> 2) | ((uint64_t)x << (2 * (k - 1)));
+  m.r = ((m.r << 2) | (uint64_t)(3 - x)) & kmask;
+}
+// forward_mer / backward_mer (kmer.hpp:70-106): d > 0 forward, d < 0 backward
+__device__ __forceinline__ void ec_dshift(ec_mer& m, int k, uint64_t kmask, int d, int x) {
+  if (d > 0) ec_shift_left(m, k, kmask, x); else ec_shift_right(m, k, kmask, x);
+}
+__device__ __forceinline__ void ec_dreplace0(ec_mer& m, int k, int d, int x) {
+  const int fs = d > 0 ? 0 : 2 * (k - 1), rs = d > 0 ? 2 * (k - 1) : 0;
+  m.f = (m.f & ~(3ull << fs)) | ((uint64_t)x << fs);
+  m.r = (m.r & ~(3ull << rs)) | ((uint64_t)(3 - x) << rs);
+}
+__device__ __forceinline__ int ec_dcode0(const ec_mer& m, int k, int d) {
+  return (int)((m.f >> (d > 0 ? 0 : 2 * (k - 1))) & 3);
+}
+
+// database_query::get_best_alternatives (mer_database.hpp:302-329): the four first probes are
+// issued together, the fold runs in code order like the upstream loop
+__device__ __forceinline__ int ec_best_alternatives(const qh_geom& g, const uint64_t* __restrict__ table,
+                                                    const ec_mer& m, int d, uint64_t counts[4], int* ucode,
+                                                    int* level) {
+  const int k = g.k;
+  qh_pos p[4];
+  uint64_t s[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ec_mer a = m;
+    ec_dreplace0(a, k, d, i);
+    p[i] = qh_locate(g, ec_canonical(a));
+    s[i] = table[p[i].home];
+  }
+  int count = 0, lvl = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    counts[i] = 0;
+    const uint64_t v = ec_resolve(g, table, p[i], s[i]);
+    const uint64_t first = v >> 1;
+    const int second = (int)(v & 1);
+    if (first > 0 && second >= lvl) {
+      if (second > lvl && count > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < i) counts[j] = 0;
+        count = 0;
+      }
+      counts[i] = first;
+      *ucode = i;
+      lvl = second;
+      ++count;
+    }
+  }
+  *level = lvl;
+  return count;
+}
+
+__device__ __forceinline__ uint64_t ec_sel4(const uint64_t c[4], int i) {
+  return i == 0 ? c[0] : i == 1 ? c[1] : i == 2 ? c[2] : c[3];
+}
+
+// ------------------------------------------------------------------ err_log
+
+// entry: pos (24 bits) | type << 24 (0 substitution, 1 truncation) | from << 25 | to << 28 (0..3, 4 = 'N')
+#define EC_POS(e) ((int)((e) & 0xFFFFFFu))
+struct ec_log {
+  uint32_t* e;
+  uint32_t n, lwin;
+  int d;
+};
+
+// err_log::check_nb_error (err_log.hpp:87-95)
+__device__ __forceinline__ bool ec_check_nb_error(ec_log& l, int window, int error) {
+  if (l.n > 0) {
+    const int back = l.d * EC_POS(l.e[l.n - 1]);
+    if (back > l.d * window)
+      while (back > l.d * EC_POS(l.e[l.lwin]) + window) l.lwin++;
+  }
+  return (uint64_t)l.n - l.lwin - 1 >= (uint64_t)(uint32_t)error;  // size_t arithmetic upstream
+}
+__device__ __forceinline__ bool ec_push(ec_log& l, uint32_t entry, int window, int error) {
+  l.e[l.n++] = entry;
+  return ec_check_nb_error(l, window, error);
+}
+// truncation as extend() calls it: backward_log::truncation logs pos - 1 in backward-counter
+// arithmetic, i.e. raw + 1 (error_correct_reads.hpp:170-172)
+__device__ __forceinline__ void ec_truncation(ec_log& l, int pos, int window, int error) {
+  ec_push(l, (uint32_t)(l.d > 0 ? pos : pos + 1) | (1u << 24), window, error);
+}
+// err_log::remove_last_window (err_log.hpp:97-106)
+__device__ __forceinline__ int ec_remove_last_window(ec_log& l, int window, int error) {
+  if (l.n == 0) return 0;
+  const int diff = l.d * (EC_POS(l.e[l.n - 1]) - EC_POS(l.e[l.lwin]));
+  l.n = l.lwin;
+  l.lwin = 0;
+  ec_check_nb_error(l, window, error);
+  return diff;
+}
+// err_log::force_truncate (err_log.hpp:75-83): drops entries with e.pos >= T(pos) in the counter's own order
+__device__ __forceinline__ void ec_force_truncate(ec_log& l, int pos, int window, int error) {
+  uint32_t w = 0;
+  for (uint32_t i = 0; i < l.n; ++i) {
+    const uint32_t e = l.e[i];
+    if (!(l.d * EC_POS(e) >= l.d * pos)) l.e[w++] = e;
+  }
+  l.n = w;
+  l.lwin = 0;
+  ec_check_nb_error(l, window, error);
+}
+
+__device__ __forceinline__ uint32_t ec_digits(uint32_t v) {
+  return 1u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) +
+         (v >= 10000000u);
+}
+// bytes operator<< (err_log.hpp:111-135) prints for n entries
+__device__ __forceinline__ uint32_t ec_log_text_bytes(const uint32_t* e, uint32_t n, uint32_t* subs) {
+  uint32_t b = n ? n - 1 : 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t x = e[i];
+    const bool trunc = (x >> 24) & 1u;
+    b += ec_digits(x & 0xFFFFFFu) + 8u;  // ":3_trunc" / ":sub:X-Y"
+    *subs += !trunc;
+  }
+  return b;
+}
+__device__ __forceinline__ uint8_t* ec_put_uint(uint8_t* w, uint32_t v) {
+  const uint32_t nd = ec_digits(v);
+  for (uint32_t i = nd; i-- > 0;) { w[i] = (uint8_t)('0' + v % 10u); v /= 10u; }
+  return w + nd;
+}
+__device__ __forceinline__ uint8_t* ec_put_log(uint8_t* w, const uint32_t* e, uint32_t n, int d) {
+  const char* const names = "ACGTN";
+  for (uint32_t i = 0; i < n; ++i) {
+    if (i) *w++ = ' ';
+    const uint32_t x = e[i];
+    w = ec_put_uint(w, x & 0xFFFFFFu);
+    if ((x >> 24) & 1u) {
+      *w++ = ':'; *w++ = d > 0 ? '3' : '5'; *w++ = '_'; *w++ = 't'; *w++ = 'r'; *w++ = 'u'; *w++ = 'n'; *w++ = 'c';
+    } else {
+      *w++ = ':'; *w++ = 's'; *w++ = 'u'; *w++ = 'b'; *w++ = ':';
+      *w++ = (uint8_t)names[(x >> 25) & 7u]; *w++ = '-'; *w++ = (uint8_t)names[(x >> 28) & 7u];
+    }
+  }
+  return w;
+}
+
+__device__ __forceinline__ uint32_t ec_error_text_bytes(uint32_t status) {
+  // "Contaminated read" / "No high quality mer" / "Entire read is an homopolymer" (error_correct_reads.cc:646-648)
+  return status == EC_ST_CONTAMINANT ? 17u : status == EC_ST_NO_START ? 19u : 29u;
+}
+
+// ------------------------------------------------------------------ the corrector
+
+struct ec_read_state {
+  ec_mer mer;
+  ec_log log;
+  int out;
+};
+
+// check_contaminant (error_correct_reads.cc:346-357)
+__device__ __forceinline__ int ec_check_contaminant(const qh_ec_dev& P, const ec_mer& m, ec_log& log, int cpos) {
+  if (P.ctable && ec_lookup(P.cg, P.ctable, ec_canonical(m)) != 0) {
+    if (P.trim_contaminant) { ec_truncation(log, cpos, P.window, P.error); return EC_TRUNCATE; }
+    return EC_ERROR;
+  }
+  return EC_OK;
+}
+
+// log_substitution (error_correct_reads.cc:360-379)
+__device__ __forceinline__ int ec_log_substitution(const qh_ec_dev& P, ec_mer& m, int d, int& out, ec_log& log,
+                                                   int cpos, int from, int to) {
+  if (from == to) return EC_OK;
+  ec_dreplace0(m, P.g.k, d, to);
+  const int cc = ec_check_contaminant(P, m, log, cpos);
+  if (cc != EC_OK) return cc;
+  const uint32_t entry = (uint32_t)cpos | ((uint32_t)(from >= 0 ? from : 4) << 25) | ((uint32_t)(to >= 0 ? to : 4) << 28);
+  if (ec_push(log, entry, P.window, P.error)) {
+    const int diff = ec_remove_last_window(log, P.window, P.error);
+    out -= d * diff;
+    ec_truncation(log, cpos - d * diff, P.window, P.error);
+    return EC_TRUNCATE;
+  }
+  return EC_OK;
+}
+
+__device__ __forceinline__ double ec_poisson_term(double lambda, unsigned i) {  // error_correct_reads.cc:53-61
+  const double facts[11] = {1, 1, 2, 6, 24, 120, 720, 5040, 40320, 362880, 3628800};
+  const double tau = 6.283185307179583;
+  if (i < 11) return exp(-lambda) * pow(lambda, (double)i) / facts[i];
+  return exp(-lambda + i) * pow(lambda / i, (double)i) / sqrt(tau * i);
+}
+
+__global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __restrict__ buf,
+                                                            const uint4* __restrict__ recs,
+                                                            const uint2* __restrict__ hdr,
+                                                            const qh_meta* __restrict__ meta, const qh_ec_dev P,
+                                                            uint8_t* __restrict__ obuf, uint32_t* __restrict__ logs,
+                                                            uint32_t* __restrict__ res,
+                                                            qh_ec_totals* __restrict__ tot) {
+  if (meta->format_err) return;
+  const uint32_t nrec = meta->nrec;
+  const int k = P.g.k;
+  const uint64_t kmask = P.g.kmask;
+  const char* const names = "ACGT";
+  uint32_t t_corrected = 0, t_skipped = 0, t_subs = 0, t_truncs = 0, t_reads = 0;
+  unsigned long long t_in = 0, t_out = 0;
+
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nrec; r += gridDim.x * blockDim.x) {
+    const uint4 rc = recs[r];
+    const uint8_t* __restrict__ seq = buf + rc.x;
+    const uint8_t* __restrict__ qual = buf + rc.z;
+    uint8_t* __restrict__ o = obuf + rc.x;
+    const int len = (int)rc.y;
+    // strict 4-line chunks: consecutive sequences are >= 2 len + 6 bytes apart, so the word range
+    // [seq_off + 4 r, + len + 4) is private to the read; host-parsed chunks carry the offset in .w
+    const uint32_t log_off = hdr ? rc.w : rc.x + 4u * r;
+    uint32_t* __restrict__ lg = logs + log_off;
+    uint32_t hlen;
+    if (hdr) hlen = hdr[r].y;
+    else {
+      const uint32_t line = r ? recs[r - 1].z + recs[r - 1].y + 1u : 0u;
+      hlen = rc.x - 1u - (line + 1u);
+    }
+
+    uint32_t status = EC_ST_OK;
+    ec_mer mer = {0, 0};
+    int in = P.skip;
+    // ---- find_starting_mer (error_correct_reads.cc:609-643); the raw characters are the output here
+    bool anchored = false;
+    while (in < len && !anchored && status == EC_ST_OK) {
+      int i = 0;
+      while (in < len && i < k) {
+        const uint8_t c = seq[in];
+        o[in] = c;
+        ++in;
+        const int x = qh_code(c);
+        if (x >= 0) { ec_shift_left(mer, k, kmask, x); ++i; }
+        else i = 0;  // upstream tests != -1 (kmer.hpp:15-22): see the oracle's header for the one deviation
+      }
+      int found = 0;
+      while (in < len) {
+        const uint64_t canon = ec_canonical(mer);
+        const bool contaminated = P.ctable && ec_lookup(P.cg, P.ctable, canon) != 0;
+        if (contaminated && !P.trim_contaminant) { status = EC_ST_CONTAMINANT; break; }
+        if (!contaminated) {
+          const uint64_t v = ec_lookup(P.g, P.table, canon);
+          const uint64_t val = (v & 1) ? v >> 1 : 0;  // get_val
+          found = (int)val >= P.anchor ? found + 1 : 0;
+          if (found >= P.good) { anchored = true; break; }
+        }
+        const uint8_t c = seq[in];
+        o[in] = c;
+        ++in;
+        const int x = qh_code(c);
+        if (x < 0) break;
+        ec_shift_left(mer, k, kmask, x);
+      }
+    }
+    if (!anchored && status == EC_ST_OK) status = EC_ST_NO_START;
+
+    int start_out = 0, end_out = 0;
+    uint32_t nf = 0, nb = 0, boff = log_off;
+    if (status == EC_ST_OK) {
+      // ---- extend forward, then backward (error_correct_reads.cc:279-316, 386-565) in one loop
+      const ec_mer anchor_mer = mer;
+      const int start_off = in;
+      uint32_t prev0;
+      {
+        const uint64_t v = ec_lookup(P.g, P.table, ec_canonical(mer));
+        prev0 = (uint32_t)((v & 1) ? v >> 1 : 0);
+      }
+      int d = +1;
+      ec_log log = {lg, 0u, 0u, +1};
+      int ip = start_off, pos = start_off, end = len, out = start_off;
+      uint32_t prev_count = prev0;
+      for (;;) {
+        bool fin = ip == end;
+        if (!fin) {
+          const uint8_t base = seq[ip];
+          if (base == '\n') { ip += d; continue; }
+          const int cpos = pos;
+          pos += d;
+          const int ori_code = qh_code(base);
+          ec_dshift(mer, k, kmask, d, ori_code >= 0 ? ori_code : 0);
+          bool emit = false;
+          if (ori_code >= 0) {
+            const int cc = ec_check_contaminant(P, mer, log, cpos);
+            if (cc == EC_TRUNCATE) fin = true;
+            else if (cc == EC_ERROR) { status = EC_ST_CONTAMINANT; break; }
+          }
+          if (!fin) {
+            uint64_t counts[4];
+            int ucode = 0, level;
+            const int count = ec_best_alternatives(P.g, P.table, mer, d, counts, &ucode, &level);
+            if (count == 0) {  // no continuation whatsoever
+              ec_truncation(log, cpos, P.window, P.error);
+              fin = true;
+            } else if (count == 1) {  // one continuation
+              prev_count = (uint32_t)ec_sel4(counts, ucode);
+              const int lc = ec_log_substitution(P, mer, d, out, log, cpos, ori_code, ucode);
+              if (lc == EC_TRUNCATE) fin = true;
+              else if (lc == EC_ERROR) { status = EC_ST_CONTAMINANT; break; }
+              else emit = true;
+            } else {
+              bool multi = true;
+              if (ori_code >= 0) {
+                const uint64_t co = ec_sel4(counts, ori_code);
+                if (co > (uint64_t)P.min_count) {
+                  if (co >= (uint32_t)P.cutoff || (int)(int8_t)qual[ip] >= (int)(int8_t)P.qual_cutoff) {
+                    emit = true; multi = false;
+                  } else {
+                    const uint64_t sum = counts[0] + counts[1] + counts[2] + counts[3];
+                    bool keep;
+                    if (P.ptab_stride) {
+                      const uint64_t bit = co * (uint64_t)P.ptab_stride + sum;
+                      keep = (P.ptab[bit >> 5] >> (bit & 31)) & 1u;
+                    } else {
+                      keep = ec_poisson_term((double)sum * P.collision_prob, (unsigned)co) < P.poisson_threshold;
+                    }
+                    if (keep) { emit = true; multi = false; }
+                  }
+                } else if (level == 0 && co == 0) {  // an error and all alternatives are low quality
+                  ec_truncation(log, cpos, P.window, P.error);
+                  fin = true; multi = false;
+                }
+              } else if (level == 0) {  // N and all alternatives are low quality
+                ec_truncation(log, cpos, P.window, P.error);
+                fin = true; multi = false;
+              }
+              if (multi) {  // several possible substitutions (error_correct_reads.cc:464-560)
+                int check_code = ori_code;
+                bool success = false;
+                uint64_t cont_counts[4] = {0, 0, 0, 0};
+                uint32_t cwcb = 0;  // continue_with_correct_base, one bit per code
+                int read_nbase_code = -1;
+                if (ip + d != end) read_nbase_code = qh_code(seq[ip + d]);
+#pragma unroll 1
+                for (int i = 0; i < 4; ++i) {
+                  const uint64_t ci = ec_sel4(counts, i);
+                  if (ci <= (uint64_t)P.min_count) continue;
+                  check_code = i;
+                  ec_mer nmer = mer;
+                  ec_dreplace0(nmer, k, d, i);
+                  ec_dshift(nmer, k, kmask, d, 0);
+                  uint64_t ncounts[4];
+                  int nucode = 0, nlevel;
+                  const int ncount = ec_best_alternatives(P.g, P.table, nmer, d, ncounts, &nucode, &nlevel);
+                  if (ncount > 0 && nlevel >= level) {
+                    if (read_nbase_code >= 0 && ec_sel4(ncounts, read_nbase_code) > 0) cwcb |= 1u << i;
+                    success = true;
+                    if (i == 0) cont_counts[0] = ci; else if (i == 1) cont_counts[1] = ci;
+                    else if (i == 2) cont_counts[2] = ci; else cont_counts[3] = ci;
+                  }
+                }
+                if (success) {
+                  check_code = -1;
+                  const uint32_t pc = prev_count <= (uint64_t)P.min_count ? 0xFFFFFFFFu : prev_count;
+                  int min_diff = INT_MAX;
+                  uint32_t cand = 0;
+                  unsigned ncand = 0;
+#pragma unroll
+                  for (int i = 0; i < 4; ++i)
+                    if (cont_counts[i] > 0) {
+                      const long long ad = llabs((long long)cont_counts[i] - (long long)pc);
+                      const int dd = (int)ad;  // upstream's (int) cast, :521
+                      if (dd < min_diff) min_diff = dd;
+                    }
+#pragma unroll
+                  for (int i = 0; i < 4; ++i)
+                    if (llabs((long long)cont_counts[i] - (long long)pc) == (long long)min_diff) {  // :526
+                      cand |= 1u << i; ++ncand; check_code = i;
+                    }
+                  if (ncand > 1 && read_nbase_code >= 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                      if ((cand >> i) & 1u) {
+                        if (!((cwcb >> i) & 1u)) --ncand;
+                        else check_code = i;
+                      }
+                  }
+                  if (ncand != 1) check_code = -1;
+                  if (check_code >= 0) {
+                    const int lc = ec_log_substitution(P, mer, d, out, log, cpos, ori_code, check_code);
+                    if (lc == EC_TRUNCATE) fin = true;
+                    else if (lc == EC_ERROR) { status = EC_ST_CONTAMINANT; break; }
+                  }
+                }
+                if (!fin) {
+                  if (ori_code < 0 && check_code < 0) {  // invalid base and no good substitution
+                    ec_truncation(log, cpos, P.window, P.error);
+                    fin = true;
+                  } else {
+                    emit = true;
+                  }
+                }
+              }
+            }
+          }
+          if (emit) { o[out] = (uint8_t)names[ec_dcode0(mer, k, d)]; out += d; }
+          ip += d;
+        }
+        if (fin) {
+          if (d > 0) {
+            end_out = out;
+            nf = log.n;
+            d = -1;
+            boff = log_off + nf + 1;  // one word left free: homo_trim may append a truncation to the forward log
+            log.e = logs + boff;
+            log.n = 0; log.lwin = 0; log.d = -1;
+            mer = anchor_mer;
+            ip = start_off - k - 1; pos = ip; end = -1; out = ip;
+            prev_count = prev0;
+          } else {
+            start_out = out + 1;
+            nb = log.n;
+            break;
+          }
+        }
+      }
+    }
+
+    // ---- homo_trim (error_correct_reads.cc:567-597)
+    if (status == EC_ST_OK && P.do_homo_trim) {
+      int max_homo_score = INT_MIN, max_pos = INT_MIN, homo_score = 0;
+      int ptr = end_out - 1;
+      int pbase = qh_code(o[ptr]);
+      for (--ptr; ptr >= start_out; --ptr) {
+        const int cbase = qh_code(o[ptr]);
+        homo_score += ((pbase == cbase) << 1) - 1;
+        pbase = cbase;
+        if (homo_score > max_homo_score) { max_homo_score = homo_score; max_pos = ptr; }
+      }
+      if (max_homo_score >= P.homo_trim) {
+        if (max_pos < start_out) status = EC_ST_HOMOPOLYMER;
+        else {
+          ec_log fl = {lg, nf, 0u, +1}, bl = {logs + boff, nb, 0u, -1};
+          ec_force_truncate(fl, max_pos, P.window, P.error);
+          ec_force_truncate(bl, max_pos, P.window, P.error);
+          ec_push(fl, (uint32_t)max_pos | (1u << 24), P.window, P.error);  // fwd_log.truncation(max_pos)
+          nf = fl.n; nb = bl.n;  // the forward log grew by at most the one word left free
+          end_out = max_pos;
+        }
+      }
+    }
+
+    // ---- sizes of this read's text in both streams
+    uint32_t fa_bytes = 0, log_bytes = 0, subs = 0;
+    ++t_reads;
+    t_in += (unsigned long long)len;
+    if (status == EC_ST_OK) {
+      const uint32_t fb = ec_log_text_bytes(lg, nf, &subs), bb = ec_log_text_bytes(logs + boff, nb, &subs);
+      const uint32_t slen = end_out > start_out ? (uint32_t)(end_out - start_out) : 0u;
+      fa_bytes = 1u + hlen + 1u + fb + 1u + bb + 1u + slen + 1u;
+      ++t_corrected;
+      t_subs += subs;
+      t_truncs += nf + nb - subs;
+      t_out += slen;
+    } else {
+      log_bytes = 8u + hlen + 2u + ec_error_text_bytes(status) + 1u;  // "Skipped " header ": " reason "\n"
+      if (P.no_discard) fa_bytes = 1u + hlen + 3u;                     // ">" header "\nN\n"
+      ++t_skipped;
+    }
+    uint32_t* __restrict__ rr = res + (size_t)r * EC_RES_WORDS;
+    reinterpret_cast<uint4*>(rr)[0] = make_uint4(status, (uint32_t)start_out, (uint32_t)end_out, nf);
+    reinterpret_cast<uint4*>(rr)[1] = make_uint4(nb, boff, fa_bytes, log_bytes);
+  }
+
+  // chunk statistics: one atomic per wave and counter
+  t_reads = wave_sum_u32(t_reads); t_corrected = wave_sum_u32(t_corrected); t_skipped = wave_sum_u32(t_skipped);
+  t_subs = wave_sum_u32(t_subs); t_truncs = wave_sum_u32(t_truncs);
+  uint32_t in_lo = wave_sum_u32((uint32_t)(t_in & 0xFFFFFu)), in_hi = wave_sum_u32((uint32_t)(t_in >> 20));
+  uint32_t out_lo = wave_sum_u32((uint32_t)(t_out & 0xFFFFFu)), out_hi = wave_sum_u32((uint32_t)(t_out >> 20));
+  if ((threadIdx.x & 63) == 0 && t_reads) {
+    atomicAdd(&tot->reads, (unsigned long long)t_reads);
+    atomicAdd(&tot->corrected, (unsigned long long)t_corrected);
+    atomicAdd(&tot->skipped, (unsigned long long)t_skipped);
+    atomicAdd(&tot->substitutions, (unsigned long long)t_subs);
+    atomicAdd(&tot->truncations, (unsigned long long)t_truncs);
+    atomicAdd(&tot->bases_in, ((unsigned long long)in_hi << 20) + in_lo);
+    atomicAdd(&tot->bases_out, ((unsigned long long)out_hi << 20) + out_lo);
+  }
+}
+
+// ------------------------------------------------------------------ output text
+
+// per block of EC_FMT_BLOCK reads: bytes of both streams
+__global__ __launch_bounds__(EC_FMT_BLOCK) void k_ec_block_sums(const uint32_t* __restrict__ res,
+                                                                const qh_meta* __restrict__ meta,
+                                                                unsigned long long* __restrict__ bsums) {
+  __shared__ unsigned long long sh[2][EC_FMT_BLOCK / 64];
+  const uint32_t nrec = meta->format_err ? 0u : meta->nrec;
+  const uint32_t r = blockIdx.x * EC_FMT_BLOCK + threadIdx.x;
+  uint32_t a = 0, b = 0;
+  if (r < nrec) { a = res[(size_t)r * EC_RES_WORDS + 6]; b = res[(size_t)r * EC_RES_WORDS + 7]; }
+  // per-read sizes are < 2^32 / 64 in any chunk the library accepts (chunk <= 4 GB), sum in 64 bits anyway
+  unsigned long long sa = a, sb = b;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = sa; sh[1][threadIdx.x >> 6] = sb; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long ta = 0, tb = 0;
+    for (int w = 0; w < EC_FMT_BLOCK / 64; ++w) { ta += sh[0][w]; tb += sh[1][w]; }
+    bsums[2 * (size_t)blockIdx.x] = ta;
+    bsums[2 * (size_t)blockIdx.x + 1] = tb;
+  }
+}
+
+// exclusive scan of the block sums (one workgroup), totals
+__global__ __launch_bounds__(1024) void k_ec_scan_blocks(unsigned long long* __restrict__ bsums, uint32_t nblocks,
+                                                         qh_ec_totals* __restrict__ tot) {
+  __shared__ unsigned long long pa[1024], pb[1024];
+  const uint32_t per = (nblocks + 1023) / 1024;
+  const uint32_t b0 = threadIdx.x * per;
+  unsigned long long sa = 0, sb = 0;
+  for (uint32_t i = b0; i < b0 + per && i < nblocks; ++i) { sa += bsums[2 * (size_t)i]; sb += bsums[2 * (size_t)i + 1]; }
+  pa[threadIdx.x] = sa; pb[threadIdx.x] = sb;
+  __syncthreads();
+  for (uint32_t o = 1; o < 1024; o <<= 1) {
+    const unsigned long long xa = threadIdx.x >= o ? pa[threadIdx.x - o] : 0, xb = threadIdx.x >= o ? pb[threadIdx.x - o] : 0;
+    __syncthreads();
+    pa[threadIdx.x] += xa; pb[threadIdx.x] += xb;
+    __syncthreads();
+  }
+  unsigned long long ra = pa[threadIdx.x] - sa, rb = pb[threadIdx.x] - sb;
+  for (uint32_t i = b0; i < b0 + per && i < nblocks; ++i) {
+    const unsigned long long xa = bsums[2 * (size_t)i], xb = bsums[2 * (size_t)i + 1];
+    bsums[2 * (size_t)i] = ra; bsums[2 * (size_t)i + 1] = rb;
+    ra += xa; rb += xb;
+  }
+  if (threadIdx.x == 1023) {
+    tot->fa_bytes = pa[1023];
+    tot->log_bytes = pb[1023];
+    tot->overflow = (pa[1023] > tot->fa_cap ? 1u : 0u) | (pb[1023] > tot->log_cap ? 2u : 0u);
+  }
+}
+
+// every read writes its text: error_correct_reads.cc:272-275 (skipped) and :334-336 (corrected)
+__global__ __launch_bounds__(EC_FMT_BLOCK) void k_ec_format(const uint8_t* __restrict__ buf,
+                                                            const uint4* __restrict__ recs,
+                                                            const uint2* __restrict__ hdr,
+                                                            const qh_meta* __restrict__ meta,
+                                                            const uint8_t* __restrict__ obuf,
+                                                            const uint32_t* __restrict__ logs,
+                                                            const uint32_t* __restrict__ res,
+                                                            const unsigned long long* __restrict__ bsums,
+                                                            const qh_ec_totals* __restrict__ tot,
+                                                            uint8_t* __restrict__ fa, uint8_t* __restrict__ lgout) {
+  __shared__ uint32_t sa[EC_FMT_BLOCK], sb[EC_FMT_BLOCK];
+  if (meta->format_err) return;
+  const uint32_t nrec = meta->nrec;
+  const uint32_t r = blockIdx.x * EC_FMT_BLOCK + threadIdx.x;
+  uint4 r0 = make_uint4(0, 0, 0, 0), r1 = make_uint4(0, 0, 0, 0);
+  if (r < nrec) {
+    r0 = reinterpret_cast<const uint4*>(res + (size_t)r * EC_RES_WORDS)[0];
+    r1 = reinterpret_cast<const uint4*>(res + (size_t)r * EC_RES_WORDS)[1];
+  }
+  sa[threadIdx.x] = r1.z; sb[threadIdx.x] = r1.w;
+  __syncthreads();
+  for (uint32_t o = 1; o < EC_FMT_BLOCK; o <<= 1) {
+    const uint32_t xa = threadIdx.x >= o ? sa[threadIdx.x - o] : 0, xb = threadIdx.x >= o ? sb[threadIdx.x - o] : 0;
+    __syncthreads();
+    sa[threadIdx.x] += xa; sb[threadIdx.x] += xb;
+    __syncthreads();
+  }
+  if (r >= nrec) return;
+  const unsigned long long fa_off = bsums[2 * (size_t)blockIdx.x] + sa[threadIdx.x] - r1.z;
+  const unsigned long long lg_off = bsums[2 * (size_t)blockIdx.x + 1] + sb[threadIdx.x] - r1.w;
+  const uint4 rc = recs[r];
+  uint32_t hoff, hlen;
+  if (hdr) { hoff = hdr[r].x; hlen = hdr[r].y; }
+  else {
+    const uint32_t line = r ? recs[r - 1].z + recs[r - 1].y + 1u : 0u;
+    hoff = line + 1u;
+    hlen = rc.x - 1u - hoff;
+  }
+  const uint8_t* __restrict__ h = buf + hoff;
+  const uint32_t status = r0.x;
+  if (status == EC_ST_OK) {
+    if (tot->overflow & 1u) return;
+    uint8_t* w = fa + fa_off;
+    *w++ = '>';
+    for (uint32_t i = 0; i < hlen; ++i) *w++ = h[i];
+    *w++ = ' ';
+    w = ec_put_log(w, logs + (hdr ? rc.w : rc.x + 4u * r), r0.w, +1);
+    *w++ = ' ';
+    w = ec_put_log(w, logs + r1.y, r1.x, -1);
+    *w++ = '\n';
+    const uint8_t* __restrict__ o = obuf + rc.x;
+    for (int i = (int)r0.y; i < (int)r0.z; ++i) *w++ = o[i];
+    *w++ = '\n';
+  } else {
+    if (!(tot->overflow & 2u)) {
+      uint8_t* w = lgout + lg_off;
+      const char* const pre = "Skipped ";
+      for (int i = 0; i < 8; ++i) *w++ = (uint8_t)pre[i];
+      for (uint32_t i = 0; i < hlen; ++i) *w++ = h[i];
+      *w++ = ':'; *w++ = ' ';
+      const char* const msg = status == EC_ST_CONTAMINANT ? "Contaminated read"
+                              : status == EC_ST_NO_START  ? "No high quality mer"
+                                                          : "Entire read is an homopolymer";
+      const uint32_t ml = ec_error_text_bytes(status);
+      for (uint32_t i = 0; i < ml; ++i) *w++ = (uint8_t)msg[i];
+      *w++ = '\n';
+    }
+    if (r1.z && !(tot->overflow & 1u)) {  // -d: ">" header "\nN\n"
+      uint8_t* w = fa + fa_off;
+      *w++ = '>';
+      for (uint32_t i = 0; i < hlen; ++i) *w++ = h[i];
+      *w++ = '\n'; *w++ = 'N'; *w++ = '\n';
+    }
+  }
+}
+
+// ------------------------------------------------------------------ host side
+
+struct qh_corrector {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  qh_query* db = nullptr;
+  qh_query* contaminant = nullptr;
+  qh_correct_params params;
+  qh_ec_dev P;
+  uint32_t* d_ptab = nullptr;
+  // chunk state
+  uint8_t* d_chunk = nullptr;  size_t chunk_cap = 0;   // staging of host-fed chunks
+  uint4* d_recs = nullptr;     size_t rec_cap = 0;
+  uint2* d_hdr = nullptr;      size_t hdr_cap = 0;
+  uint32_t* d_tiles = nullptr; size_t tile_cap = 0;
+  ushort4* d_nlplane = nullptr; size_t nlplane_cap = 0;
+  uint8_t* d_obuf = nullptr;   size_t obuf_cap = 0;
+  uint32_t* d_logs = nullptr;  size_t logs_cap = 0;
+  uint32_t* d_res = nullptr;   size_t res_cap = 0;
+  unsigned long long* d_bsums = nullptr; size_t bsums_cap = 0;
+  uint8_t* d_fa = nullptr;     size_t fa_cap = 0;
+  uint8_t* d_log = nullptr;    size_t log_cap = 0;
+  char* h_fa = nullptr;        size_t h_fa_cap = 0;    // pinned
+  char* h_log = nullptr;       size_t h_log_cap = 0;   // pinned
+  qh_meta* d_meta = nullptr;   qh_meta* h_meta = nullptr;
+  qh_ec_totals* d_tot = nullptr; qh_ec_totals* h_tot = nullptr;
+  hipEvent_t ev[4] = {};
+  // the chunk in flight (for a re-run of the format kernel and for fetch)
+  const uint8_t* cur_buf = nullptr;
+  const uint2* cur_hdr = nullptr;
+  uint32_t cur_rec_cap = 0;
+  bool pending = false;
+};
+
+static int ensure_dev(void** p, size_t* cap, size_t need, const char* what) { return qh_ensure_device(p, cap, need, what); }
+
+static int ensure_pinned(char** p, size_t* cap, size_t need) {
+  if (*cap >= need && *p) return QH_OK;
+  if (*p) { (void)hipHostFree(*p); *p = nullptr; *cap = 0; }
+  const size_t want = need + need / 8 + 4096;
+  hipError_t e = hipHostMalloc((void**)p, want, hipHostMallocDefault);
+  if (e != hipSuccess) { *p = nullptr; return qh_fail(QH_ENOMEM, "hipHostMalloc of %zu bytes failed: %s", want, hipGetErrorString(e)); }
+  *cap = want;
+  return QH_OK;
+}
+
+extern "C" void qh_corrector_destroy(qh_corrector* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  void* dptrs[] = {c->d_ptab, c->d_chunk, c->d_recs, c->d_hdr, c->d_tiles, c->d_nlplane, c->d_obuf, c->d_logs,
+                   c->d_res, c->d_bsums, c->d_fa, c->d_log, c->d_meta, c->d_tot};
+  for (void* p : dptrs) if (p) (void)hipFree(p);
+  void* hptrs[] = {c->h_fa, c->h_log, c->h_meta, c->h_tot};
+  for (void* p : hptrs) if (p) (void)hipHostFree(p);
+  for (hipEvent_t e : c->ev) if (e) (void)hipEventDestroy(e);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+static int corrector_init(qh_corrector* c) {
+  QH_HIP(hipSetDevice(c->device));
+  QH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  QH_HIP(hipMalloc((void**)&c->d_meta, sizeof(qh_meta)));
+  QH_HIP(hipHostMalloc((void**)&c->h_meta, sizeof(qh_meta), hipHostMallocDefault));
+  QH_HIP(hipMalloc((void**)&c->d_tot, sizeof(qh_ec_totals)));
+  QH_HIP(hipHostMalloc((void**)&c->h_tot, sizeof(qh_ec_totals), hipHostMallocDefault));
+  for (hipEvent_t& e : c->ev) QH_HIP(hipEventCreate(&e));
+  // Poisson decision table (error_correct_reads.cc:445-453): the test is only reached with
+  // min_count < counts[ori] < cutoff and the sum of four counts <= 4 max_val
+  const qh_correct_params& p = c->params;
+  const uint64_t max_val = c->db->g.max_val;
+  const uint64_t stride = max_val <= (1ull << 24) ? 4 * max_val + 1 : 0;
+  const uint64_t rows = p.cutoff > 0 ? (uint64_t)p.cutoff : 0;
+  if (stride && rows && rows * stride <= (1ull << 24)) {
+    std::vector<uint32_t> tab((size_t)((rows * stride + 31) / 32), 0u);
+    for (uint64_t co = 0; co < rows; ++co)
+      for (uint64_t sum = 0; sum < stride; ++sum)
+        if (qh_poisson_term((double)sum * p.collision_prob, (unsigned)co) < p.poisson_threshold) {
+          const uint64_t bit = co * stride + sum;
+          tab[(size_t)(bit >> 5)] |= 1u << (bit & 31);
+        }
+    QH_HIP(hipMalloc((void**)&c->d_ptab, tab.size() * 4));
+    QH_HIP(hipMemcpy(c->d_ptab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    c->P.ptab_stride = (int)stride;
+    c->P.ptab = c->d_ptab;
+  }
+  return QH_OK;
+}
+
+extern "C" int qh_corrector_create(qh_corrector** out, qh_query* db, qh_query* contaminant, const qh_correct_params* p) {
+  if (!out || !db || !p) return qh_fail(QH_EBADARG, "null argument");
+  *out = nullptr;
+  if (contaminant) {
+    if (contaminant->g.k != db->g.k)  // error_correct_reads.cc:703-705
+      return qh_fail(QH_EBADARG, "Contaminant mer length (%d) different than correction mer length (%d)", contaminant->g.k, db->g.k);
+    if (contaminant->device != db->device) return qh_fail(QH_EBADARG, "database and contaminant set live on different devices");
+  }
+  if (p->skip < 0 || p->good < 0 || p->anchor < 0 || p->min_count < 0 || p->cutoff < 0 || p->window < 0 || p->error < 0)
+    return qh_fail(QH_EBADARG, "negative corrector parameter");
+  if (p->window >= (1 << 23)) return qh_fail(QH_EBADARG, "window too large");
+  qh_corrector* c = new qh_corrector();
+  c->device = db->device; c->db = db; c->contaminant = contaminant; c->params = *p;
+  qh_ec_dev& P = c->P;
+  memset(&P, 0, sizeof P);
+  P.g = db->g; P.table = db->table;
+  if (contaminant) { P.cg = contaminant->g; P.ctable = contaminant->table; }
+  P.skip = p->skip; P.good = p->good; P.anchor = p->anchor; P.min_count = p->min_count; P.cutoff = p->cutoff;
+  P.window = p->window ? p->window : db->g.k;   // error_correct_reads.cc:206
+  P.error = p->error ? p->error : db->g.k / 2;  // :207
+  P.qual_cutoff = p->qual_cutoff; P.trim_contaminant = p->trim_contaminant; P.do_homo_trim = p->do_homo_trim;
+  P.homo_trim = p->homo_trim; P.no_discard = p->no_discard;
+  P.collision_prob = p->collision_prob; P.poisson_threshold = p->poisson_threshold;
+  int rc = corrector_init(c);
+  if (rc) { qh_corrector_destroy(c); return rc; }
+  *out = c;
+  return QH_OK;
+}
+
+static const size_t kMaxEcChunk = 0x7FFFF000ull;  // 31-bit offsets: positions are ints in the kernel
+
+static void launch_format(qh_corrector* c) {
+  const uint32_t nblocks = (c->cur_rec_cap + EC_FMT_BLOCK - 1) / EC_FMT_BLOCK;
+  hipLaunchKernelGGL(k_ec_format, dim3(nblocks), dim3(EC_FMT_BLOCK), 0, c->stream, c->cur_buf, c->d_recs, c->cur_hdr,
+                     c->d_meta, c->d_obuf, c->d_logs, c->d_res, c->d_bsums, c->d_tot, c->d_fa, c->d_log);
+}
+
+// record table (and nrec in d_meta) ready on the stream: correct + sizes + scan + format
+static int enqueue_correct(qh_corrector* c, const uint8_t* dev_buf, size_t len, uint32_t rec_cap, const uint2* d_hdr,
+                           size_t log_words) {
+  int rc;
+  if ((rc = ensure_dev((void**)&c->d_obuf, &c->obuf_cap, len + 16, "corrected bases"))) return rc;
+  if ((rc = ensure_dev((void**)&c->d_logs, &c->logs_cap, log_words * 4, "error logs"))) return rc;
+  if ((rc = ensure_dev((void**)&c->d_res, &c->res_cap, (size_t)rec_cap * EC_RES_WORDS * 4 + 16, "read results"))) return rc;
+  const uint32_t nblocks = (rec_cap + EC_FMT_BLOCK - 1) / EC_FMT_BLOCK;
+  if ((rc = ensure_dev((void**)&c->d_bsums, &c->bsums_cap, ((size_t)nblocks + 1) * 16, "block sums"))) return rc;
+  // first guess of the output sizes; qh_corrector_fetch grows them and writes the text again when it was short
+  if ((rc = ensure_dev((void**)&c->d_fa, &c->fa_cap, len + 4096, "corrected reads text"))) return rc;
+  if ((rc = ensure_dev((void**)&c->d_log, &c->log_cap, len / 8 + 65536, "skip log text"))) return rc;
+  qh_ec_totals z;
+  memset(&z, 0, sizeof z);
+  z.fa_cap = c->fa_cap; z.log_cap = c->log_cap;
+  *c->h_tot = z;
+  QH_HIP(hipMemcpyAsync(c->d_tot, c->h_tot, sizeof z, hipMemcpyHostToDevice, c->stream));
+  c->cur_buf = dev_buf; c->cur_hdr = d_hdr; c->cur_rec_cap = rec_cap;
+  QH_HIP(hipEventRecord(c->ev[1], c->stream));
+  unsigned grid = (rec_cap + EC_BLOCK - 1) / EC_BLOCK;
+  if (grid > 256u * 16u) grid = 256u * 16u;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_correct_reads, dim3(grid), dim3(EC_BLOCK), 0, c->stream, dev_buf, c->d_recs, d_hdr, c->d_meta, c->P,
+                     c->d_obuf, c->d_logs, c->d_res, c->d_tot);
+  QH_HIP(hipEventRecord(c->ev[2], c->stream));
+  hipLaunchKernelGGL(k_ec_block_sums, dim3(nblocks ? nblocks : 1), dim3(EC_FMT_BLOCK), 0, c->stream, c->d_res, c->d_meta,
+                     c->d_bsums);
+  hipLaunchKernelGGL(k_ec_scan_blocks, dim3(1), dim3(1024), 0, c->stream, c->d_bsums, nblocks ? nblocks : 1, c->d_tot);
+  launch_format(c);
+  QH_HIP(hipEventRecord(c->ev[3], c->stream));
+  QH_HIP(hipGetLastError());
+  c->pending = true;
+  return QH_OK;
+}
+
+static int correct_device_on(qh_corrector* c, const void* dev_buf, size_t len) {
+  if (len == 0) return qh_fail(QH_EBADARG, "empty chunk");
+  if (!dev_buf || ((uintptr_t)dev_buf & 15)) return qh_fail(QH_EBADARG, "device chunk must be non-null and 16-byte aligned");
+  if (len > kMaxEcChunk) return qh_fail(QH_EBADARG, "chunk larger than %zu bytes", kMaxEcChunk);
+  QH_HIP(hipSetDevice(c->device));
+  int rc;
+  const size_t ntiles = (len + QH_TILE_BYTES - 1) / QH_TILE_BYTES;
+  const size_t rec_cap = len / 16 + 16;
+  if ((rc = ensure_dev((void**)&c->d_tiles, &c->tile_cap, (ntiles + 1) * 4, "tile counts"))) return rc;
+  if ((rc = ensure_dev((void**)&c->d_recs, &c->rec_cap, rec_cap * 16, "record table"))) return rc;
+  if ((rc = ensure_dev((void**)&c->d_nlplane, &c->nlplane_cap, (len / 16 + 2) * 8, "newline plane"))) return rc;
+  QH_HIP(hipEventRecord(c->ev[0], c->stream));
+  QH_HIP(hipMemsetAsync(c->d_meta, 0, sizeof(qh_meta), c->stream));
+  qh_launch_index_fastq((const uint8_t*)dev_buf, len, c->d_tiles, c->d_nlplane, c->d_recs, (uint32_t)rec_cap, c->d_meta,
+                        nullptr, 0, c->stream);
+  // log words: seq_off + 4 r + len + 4 <= len_chunk + 4 nrec + 8, nrec <= len / 6 for non-empty 4-line records
+  return enqueue_correct(c, (const uint8_t*)dev_buf, len, (uint32_t)rec_cap, nullptr, len + 4 * (len / 6 + 2) + 64);
+}
+
+extern "C" int qh_corrector_correct_device(qh_corrector* c, const void* dev_buf, size_t len, void* hip_stream) {
+  if (!c) return qh_fail(QH_EBADARG, "null handle");
+  if (hip_stream) {  // order this chunk after the caller's stream
+    QH_HIP(hipSetDevice(c->device));
+    hipEvent_t e;
+    QH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipError_t er = hipEventRecord(e, (hipStream_t)hip_stream);
+    if (er == hipSuccess) er = hipStreamWaitEvent(c->stream, e, 0);
+    (void)hipEventDestroy(e);
+    if (er != hipSuccess) return qh_fail(QH_EHIP, "ordering after the caller's stream failed: %s", hipGetErrorString(er));
+  }
+  return correct_device_on(c, dev_buf, len);
+}
+
+static const char* format_error_text(uint32_t err) {
+  if (err & QH_FMT_NO_AT) return "Invalid fastq file: header missing";
+  if (err & QH_FMT_LINES_MOD4) return "chunk is not made of whole 4-line records";
+  if (err & QH_FMT_NO_PLUS) return "Invalid fastq file: '+' line missing (multi-line record?)";
+  if (err & QH_FMT_LEN_MISMATCH) return "Invalid fastq file: wrong number of quals";
+  if (err & QH_FMT_EMPTY_TAIL) return "empty read";
+  return "too many records";
+}
+
+extern "C" int qh_corrector_fetch(qh_corrector* c, const char** fa, size_t* fa_len, const char** log, size_t* log_len,
+                                  qh_correct_stats* stats) {
+  if (!c) return qh_fail(QH_EBADARG, "null handle");
+  if (fa) *fa = nullptr;
+  if (fa_len) *fa_len = 0;
+  if (log) *log = nullptr;
+  if (log_len) *log_len = 0;
+  if (stats) memset(stats, 0, sizeof *stats);
+  if (!c->pending) return QH_OK;
+  c->pending = false;
+  QH_HIP(hipSetDevice(c->device));
+  QH_HIP(hipMemcpyAsync(c->h_meta, c->d_meta, sizeof(qh_meta), hipMemcpyDeviceToHost, c->stream));
+  QH_HIP(hipMemcpyAsync(c->h_tot, c->d_tot, sizeof(qh_ec_totals), hipMemcpyDeviceToHost, c->stream));
+  QH_HIP(hipStreamSynchronize(c->stream));
+  if (c->h_meta->format_err)
+    return qh_fail(QH_EFORMAT, "%s (record %u of the chunk)", format_error_text(c->h_meta->format_err), c->h_meta->first_bad);
+  if (c->h_tot->overflow) {  // the first guess was short: grow and write the text again
+    int rc;
+    if ((rc = ensure_dev((void**)&c->d_fa, &c->fa_cap, c->h_tot->fa_bytes + 16, "corrected reads text"))) return rc;
+    if ((rc = ensure_dev((void**)&c->d_log, &c->log_cap, c->h_tot->log_bytes + 16, "skip log text"))) return rc;
+    c->h_tot->fa_cap = c->fa_cap; c->h_tot->log_cap = c->log_cap; c->h_tot->overflow = 0;
+    QH_HIP(hipMemcpyAsync(c->d_tot, c->h_tot, sizeof(qh_ec_totals), hipMemcpyHostToDevice, c->stream));
+    launch_format(c);
+    QH_HIP(hipGetLastError());
+  }
+  const size_t nfa = (size_t)c->h_tot->fa_bytes, nlog = (size_t)c->h_tot->log_bytes;
+  int rc;
+  if ((rc = ensure_pinned(&c->h_fa, &c->h_fa_cap, nfa + 1))) return rc;
+  if ((rc = ensure_pinned(&c->h_log, &c->h_log_cap, nlog + 1))) return rc;
+  if (nfa) QH_HIP(hipMemcpyAsync(c->h_fa, c->d_fa, nfa, hipMemcpyDeviceToHost, c->stream));
+  if (nlog) QH_HIP(hipMemcpyAsync(c->h_log, c->d_log, nlog, hipMemcpyDeviceToHost, c->stream));
+  QH_HIP(hipStreamSynchronize(c->stream));
+  c->h_fa[nfa] = 0; c->h_log[nlog] = 0;
+  if (fa) *fa = c->h_fa;
+  if (fa_len) *fa_len = nfa;
+  if (log) *log = c->h_log;
+  if (log_len) *log_len = nlog;
+  if (stats) {
+    stats->reads = c->h_tot->reads; stats->corrected = c->h_tot->corrected; stats->skipped = c->h_tot->skipped;
+    stats->substitutions = c->h_tot->substitutions; stats->truncations = c->h_tot->truncations;
+    stats->bases_in = c->h_tot->bases_in; stats->bases_out = c->h_tot->bases_out;
+  }
+  return QH_OK;
+}
+
+extern "C" int qh_corrector_kernel_time(qh_corrector* c, double* correct_ms, double* chunk_ms) {
+  if (!c) return qh_fail(QH_EBADARG, "null handle");
+  QH_HIP(hipSetDevice(c->device));
+  QH_HIP(hipEventSynchronize(c->ev[3]));
+  float a = 0, b = 0;
+  QH_HIP(hipEventElapsedTime(&a, c->ev[1], c->ev[2]));
+  QH_HIP(hipEventElapsedTime(&b, c->ev[0], c->ev[3]));
+  if (correct_ms) *correct_ms = a;
+  if (chunk_ms) *chunk_ms = b;
+  return QH_OK;
+}
+
+extern "C" int qh_corrector_correct_fastq(qh_corrector* c, const char* buf, size_t len, int final_chunk, size_t* consumed) {
+  if (!c) return qh_fail(QH_EBADARG, "null handle");
+  if (consumed) *consumed = 0;
+  if (len == 0) return QH_OK;
+  if (!buf) return qh_fail(QH_EBADARG, "null chunk");
+  if (len > kMaxEcChunk / 2) return qh_fail(QH_EBADARG, "chunk larger than %zu bytes", kMaxEcChunk / 2);
+  QH_HIP(hipSetDevice(c->device));
+  QH_HIP(hipStreamSynchronize(c->stream));  // staging buffers are reused
+  c->pending = false;
+  int rc;
+  // fast path: the leading whole 4-line groups, indexed and checked on the GPU
+  const size_t used = qh_fastq_4line_prefix(buf, len, final_chunk);
+  if (used) {
+    if ((rc = ensure_dev((void**)&c->d_chunk, &c->chunk_cap, used + 32, "chunk staging"))) return rc;
+    QH_HIP(hipMemcpyAsync(c->d_chunk, buf, used, hipMemcpyHostToDevice, c->stream));
+    if ((rc = correct_device_on(c, c->d_chunk, used))) return rc;
+    QH_HIP(hipMemcpyAsync(c->h_meta, c->d_meta, sizeof(qh_meta), hipMemcpyDeviceToHost, c->stream));
+    QH_HIP(hipStreamSynchronize(c->stream));
+    if (!c->h_meta->format_err) {
+      if (consumed) *consumed = used;
+      return QH_OK;
+    }
+    c->pending = false;  // rejected: nothing was corrected (the kernels return on format_err)
+  }
+  // sequential host parser with Jellyfish's rules (multi-line records)
+  std::vector<qh_record> recs;
+  std::vector<qh_hdr> hdrs;
+  std::string scratch;
+  size_t eaten = 0;
+  if ((rc = qh_parse_fastq_host(buf, len, final_chunk != 0, recs, scratch, &eaten, &hdrs))) return rc;
+  if (consumed) *consumed = eaten;
+  if (recs.empty()) return QH_OK;
+  const size_t eo = (eaten + 15) & ~(size_t)15;
+  if ((rc = ensure_dev((void**)&c->d_chunk, &c->chunk_cap, eo + scratch.size() + 32, "chunk staging"))) return rc;
+  size_t log_words = 0;
+  for (size_t i = 0; i < recs.size(); ++i) {
+    if (recs[i].reserved & 1u) recs[i].seq_off += (uint32_t)eo;
+    if (recs[i].reserved & 2u) recs[i].qual_off += (uint32_t)eo;
+    if (log_words + recs[i].len + 4 > 0xFFFFFFF0ull) return qh_fail(QH_EBADARG, "chunk too large for the error logs");
+    recs[i].reserved = (uint32_t)log_words;  // becomes .w of the device record: the read's log offset
+    log_words += (size_t)recs[i].len + 4;
+  }
+  if ((rc = ensure_dev((void**)&c->d_recs, &c->rec_cap, (recs.size() + 1) * 16, "record table"))) return rc;
+  if ((rc = ensure_dev((void**)&c->d_hdr, &c->hdr_cap, (recs.size() + 1) * 8, "header table"))) return rc;
+  QH_HIP(hipMemcpyAsync(c->d_chunk, buf, eaten, hipMemcpyHostToDevice, c->stream));
+  if (!scratch.empty()) QH_HIP(hipMemcpyAsync(c->d_chunk + eo, scratch.data(), scratch.size(), hipMemcpyHostToDevice, c->stream));
+  static_assert(sizeof(qh_record) == 16 && sizeof(qh_hdr) == 8, "host records must match the device tables");
+  QH_HIP(hipMemcpyAsync(c->d_recs, recs.data(), recs.size() * 16, hipMemcpyHostToDevice, c->stream));
+  QH_HIP(hipMemcpyAsync(c->d_hdr, hdrs.data(), hdrs.size() * 8, hipMemcpyHostToDevice, c->stream));
+  memset(c->h_meta, 0, sizeof(qh_meta));
+  c->h_meta->nrec = (uint32_t)recs.size();
+  QH_HIP(hipMemcpyAsync(c->d_meta, c->h_meta, sizeof(qh_meta), hipMemcpyHostToDevice, c->stream));
+  QH_HIP(hipEventRecord(c->ev[0], c->stream));
+  rc = enqueue_correct(c, c->d_chunk, eo + scratch.size() + 16, (uint32_t)recs.size(), c->d_hdr, log_words + 16);
+  QH_HIP(hipStreamSynchronize(c->stream));  // recs / hdrs / scratch are locals
+  return rc;
+}

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <mutex>
 #include <string>
+#include <vector>
 #include "qh_host.h"
 #include "qh_kernels.h"
 
@@ -64,5 +65,11 @@ int qh_query_from_table(int device, uint64_t* table, const qh_geom& g, qh_query*
 int qh_table_dump(int device, hipStream_t stream, const uint64_t* table, const qh_geom& g, qh_meta* d_meta,
                   qh_meta* h_meta, uint64_t* mers, uint64_t* vals, uint64_t cap, uint64_t* n);
 int qh_ensure_device(void** p, size_t* cap, size_t need, const char* what);
+
+// Sequential FASTQ parser with jellyfish::whole_sequence_parser's rules (qh_build.hip). hdrs (optional)
+// receives the header text of every record: offset of the byte after '@' and its length.
+struct qh_hdr { uint32_t off, len; };
+int qh_parse_fastq_host(const char* buf, size_t len, bool final_chunk, std::vector<qh_record>& recs,
+                        std::string& scratch, size_t* consumed, std::vector<qh_hdr>* hdrs);
 
 extern "C" int qh_build_write_shard(qh_build* h, const char* path, int argc, const char* const* argv, int write_header);
