@@ -64,72 +64,155 @@ struct qh_ec_totals {
 
 // ------------------------------------------------------------------ lookups
 
-struct ec_slot4 { qh_pos p[4]; uint64_t s[4]; };
+// The k-mer under the read head as bit planes, the form the table hashes (qh_spec.h: plane key =
+// low code bits | high code bits << k): a0/a1 = low/high code bits of the strand that is being
+// extended at its low end, b0/b1 of its reverse complement, base i at bit i. Extending backwards on
+// the forward strand IS extending forwards on the reverse strand with complemented codes, so one
+// direction-free set of operations serves forward_mer and backward_mer (kmer.hpp:70-106): a = the
+// forward mer and y = the base code when d > 0, a = the reverse complement and y = 3 - code when d < 0.
+// The 2-bit interleaved mer is never built: shifting a base in costs 8 32-bit operations, the
+// canonical form ~10 (qh_canonical_planes) and the position hash is the table's own 3 multiplies.
+struct ec_mer { uint32_t a0, a1, b0, b1; };
 
-// first probe of a lookup already loaded (s): finish database_query::operator[]
-__device__ __forceinline__ uint64_t ec_resolve(const qh_geom& g, const uint64_t* __restrict__ table, const qh_pos& p,
-                                               uint64_t s) {
-  if (p.shard != (uint32_t)g.shard_id) return 0;
-  const uint64_t wmask = qh_low_mask(g.wbits);
-  const uint64_t base = p.home & ~wmask;
-  for (uint32_t i = 0;;) {
-    if (s == 0) return 0;
-    if ((s >> g.vbits) == (p.tag0 | (i + 1))) return s & g.vmask;
-    if (++i > (uint32_t)g.max_reprobe) return 0;
-    s = table[base | ((p.home + i) & wmask)];
+__device__ __forceinline__ void ec_shift(ec_mer& m, int k, uint32_t km, uint32_t y) {
+  const uint32_t ny = y ^ 3u;
+  m.a0 = ((m.a0 << 1) | (y & 1u)) & km;
+  m.a1 = ((m.a1 << 1) | (y >> 1)) & km;
+  m.b0 = (m.b0 >> 1) | ((ny & 1u) << (k - 1));
+  m.b1 = (m.b1 >> 1) | ((ny >> 1) << (k - 1));
+}
+__device__ __forceinline__ void ec_replace0(ec_mer& m, int k, uint32_t y) {  // kmer.hpp:47-50
+  const uint32_t ny = y ^ 3u, top = 1u << (k - 1);
+  m.a0 = (m.a0 & ~1u) | (y & 1u);
+  m.a1 = (m.a1 & ~1u) | (y >> 1);
+  m.b0 = (m.b0 & ~top) | ((ny & 1u) << (k - 1));
+  m.b1 = (m.b1 & ~top) | ((ny >> 1) << (k - 1));
+}
+// hash of mer.canonical() (kmer.hpp:43): position and remainder of the key in any table of this k
+__device__ __forceinline__ uint64_t ec_hash(const ec_mer& m, int k) {
+  uint32_t c0, c1;
+  qh_canonical_planes(m.a0, m.a1, m.b0, m.b1, &c0, &c1);
+  return qh_mix2(c0, c1, k);
+}
+__device__ __forceinline__ uint32_t ec_code0(const ec_mer& m) { return (m.a0 & 1u) | ((m.a1 & 1u) << 1); }
+
+// NARROW: the value field and the remainder + probe fields each fit 32 bits (k = 24 at genome-size
+// tables): counts and tag compares are 32-bit. Otherwise everything is 64-bit.
+template <bool NARROW> struct ec_word;
+template <> struct ec_word<true> { typedef uint32_t type; };
+template <> struct ec_word<false> { typedef uint64_t type; };
+
+// database_query::operator[] for N hashed mers at once. Probing is linear inside a 2^wbits-slot
+// window, so consecutive probes are consecutive words: every round loads the 32-byte group of four
+// slots that holds the next probes of each unresolved lookup, and all N lookups advance in the same
+// round. What bounds a read is the number of dependent memory round trips per base; three of the four
+// alternatives of get_best_alternatives are normally ABSENT, and an unsuccessful search at load 0.54
+// walks 2.9 slots on average with a long tail, of which the wave pays the maximum over its 64 lanes.
+// One slot per round and one lookup after the other cost about 60 round trips per base; this form 3-4.
+struct ec_group { uint64_t a, b, c, d; };
+
+template <int N, bool NARROW>
+__device__ __forceinline__ void ec_lookup_wide(const qh_geom& g, const uint64_t* __restrict__ table,
+                                               const uint64_t (&h)[N], typename ec_word<NARROW>::type (&v)[N]) {
+  typedef typename ec_word<NARROW>::type W;
+  const uint32_t wmask = (1u << g.wbits) - 1u;
+  uint64_t gaddr[N];  // slot index of the group's first slot
+  W tag0[N];
+  int pi[N];          // probe index of the group's first slot (negative: slots before the home slot)
+  bool pend[N];
+  ec_group grp[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    const qh_pos p = qh_locate_hash(g, h[n]);
+    v[n] = 0;
+    pend[n] = p.shard == (uint32_t)g.shard_id;
+    const uint32_t ho = (uint32_t)p.home & wmask;
+    tag0[n] = (W)p.tag0;
+    gaddr[n] = p.home & ~(uint64_t)3;
+    pi[n] = -(int)(ho & 3u);
+    if (pend[n]) grp[n] = *reinterpret_cast<const ec_group*>(table + gaddr[n]);
+  }
+  for (;;) {
+    bool any = false;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      if (!pend[n]) continue;
+      const uint64_t s4[4] = {grp[n].a, grp[n].b, grp[n].c, grp[n].d};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = pi[n] + j;
+        if (pend[n] && idx >= 0) {
+          if (idx > g.max_reprobe || s4[j] == 0) pend[n] = false;
+          else if ((W)(s4[j] >> g.vbits) == (tag0[n] | (W)(idx + 1))) { v[n] = (W)s4[j] & (W)g.vmask; pend[n] = false; }
+        }
+      }
+      if (pend[n]) {  // next group of the window (wraps at the window's end)
+        gaddr[n] = (gaddr[n] & ~(uint64_t)wmask) | (((uint32_t)gaddr[n] + 4u) & wmask);
+        pi[n] += 4;
+        any = true;
+      }
+    }
+    if (!any) break;
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+      if (pend[n]) grp[n] = *reinterpret_cast<const ec_group*>(table + gaddr[n]);
   }
 }
 
-__device__ __forceinline__ uint64_t ec_lookup(const qh_geom& g, const uint64_t* __restrict__ table, uint64_t canon) {
-  const qh_pos p = qh_locate(g, canon);
-  return ec_resolve(g, table, p, table[p.home]);
+// tables of fewer than four slots per window: one slot at a time
+__device__ __forceinline__ uint64_t ec_lookup_narrow_table(const qh_geom& g, const uint64_t* __restrict__ table, uint64_t h) {
+  const qh_pos p = qh_locate_hash(g, h);
+  if (p.shard != (uint32_t)g.shard_id) return 0;
+  const uint64_t wmask = qh_low_mask(g.wbits);
+  const uint64_t base = p.home & ~wmask;
+  for (uint32_t i = 0; i <= (uint32_t)g.max_reprobe; ++i) {
+    const uint64_t s = table[base | ((p.home + i) & wmask)];
+    if (s == 0) return 0;
+    if ((s >> g.vbits) == (p.tag0 | (i + 1))) return s & g.vmask;
+  }
+  return 0;
 }
 
-// kmer_t (kmer.hpp:11-61) as two registers
-struct ec_mer { uint64_t f, r; };
-__device__ __forceinline__ uint64_t ec_canonical(const ec_mer& m) { return m.f < m.r ? m.f : m.r; }
-__device__ __forceinline__ void ec_shift_left(ec_mer& m, int k, uint64_t kmask, int x) {
-  m.f = ((m.f << 2) | (uint64_t)x) & kmask;
-  m.r = (m.r >> 2) | ((uint64_t)(3 - x) << (2 * (k - 1)));
-}
-__device__ __forceinline__ void ec_shift_right(ec_mer& m, int k, uint64_t kmask, int x) {
-  m.f = (m.f >> 2) | ((uint64_t)x << (2 * (k - 1)));
-  m.r = ((m.r << 2) | (uint64_t)(3 - x)) & kmask;
-}
-// forward_mer / backward_mer (kmer.hpp:70-106): d > 0 forward, d < 0 backward
-__device__ __forceinline__ void ec_dshift(ec_mer& m, int k, uint64_t kmask, int d, int x) {
-  if (d > 0) ec_shift_left(m, k, kmask, x); else ec_shift_right(m, k, kmask, x);
-}
-__device__ __forceinline__ void ec_dreplace0(ec_mer& m, int k, int d, int x) {
-  const int fs = d > 0 ? 0 : 2 * (k - 1), rs = d > 0 ? 2 * (k - 1) : 0;
-  m.f = (m.f & ~(3ull << fs)) | ((uint64_t)x << fs);
-  m.r = (m.r & ~(3ull << rs)) | ((uint64_t)(3 - x) << rs);
-}
-__device__ __forceinline__ int ec_dcode0(const ec_mer& m, int k, int d) {
-  return (int)((m.f >> (d > 0 ? 0 : 2 * (k - 1))) & 3);
+template <bool NARROW>
+__device__ __forceinline__ typename ec_word<NARROW>::type ec_lookup(const qh_geom& g, const uint64_t* __restrict__ table,
+                                                                     uint64_t h) {
+  typedef typename ec_word<NARROW>::type W;
+  if (g.wbits < 2) return (W)ec_lookup_narrow_table(g, table, h);
+  const uint64_t hh[1] = {h};
+  W v[1];
+  ec_lookup_wide<1, NARROW>(g, table, hh, v);
+  return v[0];
 }
 
 // database_query::get_best_alternatives (mer_database.hpp:302-329): the four first probes are
-// issued together, the fold runs in code order like the upstream loop
+// issued together, the fold runs in the order of the forward strand's codes like the upstream loop
+// (the candidate with a-strand code y is the forward code y when d > 0 and 3 - y when d < 0)
+template <bool NARROW>
 __device__ __forceinline__ int ec_best_alternatives(const qh_geom& g, const uint64_t* __restrict__ table,
-                                                    const ec_mer& m, int d, uint64_t counts[4], int* ucode,
-                                                    int* level) {
+                                                    const ec_mer& m, int d, typename ec_word<NARROW>::type (&counts)[4],
+                                                    int* ucode, int* level) {
+  typedef typename ec_word<NARROW>::type W;
   const int k = g.k;
-  qh_pos p[4];
-  uint64_t s[4];
+  uint64_t h[4];
+  W w[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int y = 0; y < 4; ++y) {
     ec_mer a = m;
-    ec_dreplace0(a, k, d, i);
-    p[i] = qh_locate(g, ec_canonical(a));
-    s[i] = table[p[i].home];
+    ec_replace0(a, k, (uint32_t)y);
+    h[y] = ec_hash(a, k);
+  }
+  if (g.wbits < 2) {
+#pragma unroll
+    for (int y = 0; y < 4; ++y) w[y] = (W)ec_lookup_narrow_table(g, table, h[y]);
+  } else {
+    ec_lookup_wide<4, NARROW>(g, table, h, w);
   }
   int count = 0, lvl = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     counts[i] = 0;
-    const uint64_t v = ec_resolve(g, table, p[i], s[i]);
-    const uint64_t first = v >> 1;
+    const W v = d > 0 ? w[i] : w[3 - i];
+    const W first = v >> 1;
     const int second = (int)(v & 1);
     if (first > 0 && second >= lvl) {
       if (second > lvl && count > 0) {
@@ -148,7 +231,8 @@ __device__ __forceinline__ int ec_best_alternatives(const qh_geom& g, const uint
   return count;
 }
 
-__device__ __forceinline__ uint64_t ec_sel4(const uint64_t c[4], int i) {
+template <typename W>
+__device__ __forceinline__ W ec_sel4(const W (&c)[4], int i) {
   return i == 0 ? c[0] : i == 1 ? c[1] : i == 2 ? c[2] : c[3];
 }
 
@@ -244,27 +328,23 @@ __device__ __forceinline__ uint32_t ec_error_text_bytes(uint32_t status) {
 
 // ------------------------------------------------------------------ the corrector
 
-struct ec_read_state {
-  ec_mer mer;
-  ec_log log;
-  int out;
-};
-
 // check_contaminant (error_correct_reads.cc:346-357)
+template <bool NARROW>
 __device__ __forceinline__ int ec_check_contaminant(const qh_ec_dev& P, const ec_mer& m, ec_log& log, int cpos) {
-  if (P.ctable && ec_lookup(P.cg, P.ctable, ec_canonical(m)) != 0) {
+  if (P.ctable && ec_lookup<NARROW>(P.cg, P.ctable, ec_hash(m, P.g.k)) != 0) {
     if (P.trim_contaminant) { ec_truncation(log, cpos, P.window, P.error); return EC_TRUNCATE; }
     return EC_ERROR;
   }
   return EC_OK;
 }
 
-// log_substitution (error_correct_reads.cc:360-379)
+// log_substitution (error_correct_reads.cc:360-379); from / to are codes of the forward strand
+template <bool NARROW>
 __device__ __forceinline__ int ec_log_substitution(const qh_ec_dev& P, ec_mer& m, int d, int& out, ec_log& log,
                                                    int cpos, int from, int to) {
   if (from == to) return EC_OK;
-  ec_dreplace0(m, P.g.k, d, to);
-  const int cc = ec_check_contaminant(P, m, log, cpos);
+  ec_replace0(m, P.g.k, (uint32_t)(d > 0 ? to : 3 - to));
+  const int cc = ec_check_contaminant<NARROW>(P, m, log, cpos);
   if (cc != EC_OK) return cc;
   const uint32_t entry = (uint32_t)cpos | ((uint32_t)(from >= 0 ? from : 4) << 25) | ((uint32_t)(to >= 0 ? to : 4) << 28);
   if (ec_push(log, entry, P.window, P.error)) {
@@ -283,17 +363,21 @@ __device__ __forceinline__ double ec_poisson_term(double lambda, unsigned i) {  
   return exp(-lambda + i) * pow(lambda / i, (double)i) / sqrt(tau * i);
 }
 
+template <bool NARROW>
 __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __restrict__ buf,
                                                             const uint4* __restrict__ recs,
                                                             const uint2* __restrict__ hdr,
-                                                            const qh_meta* __restrict__ meta, const qh_ec_dev P,
+                                                            const qh_meta* __restrict__ meta,
+                                                            const qh_ec_dev* __restrict__ Pp,
                                                             uint8_t* __restrict__ obuf, uint32_t* __restrict__ logs,
                                                             uint32_t* __restrict__ res,
                                                             qh_ec_totals* __restrict__ tot) {
+  typedef typename ec_word<NARROW>::type W;
   if (meta->format_err) return;
+  const qh_ec_dev& P = *Pp;
   const uint32_t nrec = meta->nrec;
   const int k = P.g.k;
-  const uint64_t kmask = P.g.kmask;
+  const uint32_t km = (uint32_t)((1ull << k) - 1);
   const char* const names = "ACGT";
   uint32_t t_corrected = 0, t_skipped = 0, t_subs = 0, t_truncs = 0, t_reads = 0;
   unsigned long long t_in = 0, t_out = 0;
@@ -301,13 +385,11 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
   for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nrec; r += gridDim.x * blockDim.x) {
     const uint4 rc = recs[r];
     const uint8_t* __restrict__ seq = buf + rc.x;
-    const uint8_t* __restrict__ qual = buf + rc.z;
     uint8_t* __restrict__ o = obuf + rc.x;
     const int len = (int)rc.y;
     // strict 4-line chunks: consecutive sequences are >= 2 len + 6 bytes apart, so the word range
     // [seq_off + 4 r, + len + 4) is private to the read; host-parsed chunks carry the offset in .w
     const uint32_t log_off = hdr ? rc.w : rc.x + 4u * r;
-    uint32_t* __restrict__ lg = logs + log_off;
     uint32_t hlen;
     if (hdr) hlen = hdr[r].y;
     else {
@@ -316,7 +398,7 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
     }
 
     uint32_t status = EC_ST_OK;
-    ec_mer mer = {0, 0};
+    ec_mer mer = {0, 0, 0, 0};
     int in = P.skip;
     // ---- find_starting_mer (error_correct_reads.cc:609-643); the raw characters are the output here
     bool anchored = false;
@@ -327,17 +409,17 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
         o[in] = c;
         ++in;
         const int x = qh_code(c);
-        if (x >= 0) { ec_shift_left(mer, k, kmask, x); ++i; }
+        if (x >= 0) { ec_shift(mer, k, km, (uint32_t)x); ++i; }
         else i = 0;  // upstream tests != -1 (kmer.hpp:15-22): see the oracle's header for the one deviation
       }
       int found = 0;
       while (in < len) {
-        const uint64_t canon = ec_canonical(mer);
-        const bool contaminated = P.ctable && ec_lookup(P.cg, P.ctable, canon) != 0;
+        const uint64_t h = ec_hash(mer, k);
+        const bool contaminated = P.ctable && ec_lookup<NARROW>(P.cg, P.ctable, h) != 0;
         if (contaminated && !P.trim_contaminant) { status = EC_ST_CONTAMINANT; break; }
         if (!contaminated) {
-          const uint64_t v = ec_lookup(P.g, P.table, canon);
-          const uint64_t val = (v & 1) ? v >> 1 : 0;  // get_val
+          const W v = ec_lookup<NARROW>(P.g, P.table, h);
+          const W val = (v & 1) ? v >> 1 : 0;  // get_val
           found = (int)val >= P.anchor ? found + 1 : 0;
           if (found >= P.good) { anchored = true; break; }
         }
@@ -346,7 +428,7 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
         ++in;
         const int x = qh_code(c);
         if (x < 0) break;
-        ec_shift_left(mer, k, kmask, x);
+        ec_shift(mer, k, km, (uint32_t)x);
       }
     }
     if (!anchored && status == EC_ST_OK) status = EC_ST_NO_START;
@@ -359,38 +441,45 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
       const int start_off = in;
       uint32_t prev0;
       {
-        const uint64_t v = ec_lookup(P.g, P.table, ec_canonical(mer));
+        const W v = ec_lookup<NARROW>(P.g, P.table, ec_hash(mer, k));
         prev0 = (uint32_t)((v & 1) ? v >> 1 : 0);
       }
       int d = +1;
-      ec_log log = {lg, 0u, 0u, +1};
+      ec_log log = {logs + log_off, 0u, 0u, +1};
       int ip = start_off, pos = start_off, end = len, out = start_off;
       uint32_t prev_count = prev0;
+      // the character under the head is loaded one step ahead: it never waits behind the lookups
+      uint8_t nbase = ip != end ? seq[ip] : (uint8_t)0;
       for (;;) {
         bool fin = ip == end;
         if (!fin) {
-          const uint8_t base = seq[ip];
+          const uint8_t base = nbase;
+          nbase = ip + d != end ? seq[ip + d] : (uint8_t)0;
           if (base == '\n') { ip += d; continue; }
           const int cpos = pos;
           pos += d;
           const int ori_code = qh_code(base);
-          ec_dshift(mer, k, kmask, d, ori_code >= 0 ? ori_code : 0);
+          const uint32_t x = ori_code >= 0 ? (uint32_t)ori_code : 0u;
+          ec_shift(mer, k, km, d > 0 ? x : 3u - x);
           bool emit = false;
-          if (ori_code >= 0) {
-            const int cc = ec_check_contaminant(P, mer, log, cpos);
+          if (ori_code >= 0 && P.ctable) {
+            const int cc = ec_check_contaminant<NARROW>(P, mer, log, cpos);
             if (cc == EC_TRUNCATE) fin = true;
             else if (cc == EC_ERROR) { status = EC_ST_CONTAMINANT; break; }
           }
           if (!fin) {
-            uint64_t counts[4];
+            W counts[4];
             int ucode = 0, level;
-            const int count = ec_best_alternatives(P.g, P.table, mer, d, counts, &ucode, &level);
-            if (count == 0) {  // no continuation whatsoever
+            const int count = ec_best_alternatives<NARROW>(P.g, P.table, mer, d, counts, &ucode, &level);
+            if (count == 1 && ucode == ori_code) {  // the read's base is the one continuation: the common case
+              prev_count = (uint32_t)ec_sel4(counts, ucode);
+              emit = true;
+            } else if (count == 0) {  // no continuation whatsoever
               ec_truncation(log, cpos, P.window, P.error);
               fin = true;
-            } else if (count == 1) {  // one continuation
+            } else if (count == 1) {  // one continuation: a substitution
               prev_count = (uint32_t)ec_sel4(counts, ucode);
-              const int lc = ec_log_substitution(P, mer, d, out, log, cpos, ori_code, ucode);
+              const int lc = ec_log_substitution<NARROW>(P, mer, d, out, log, cpos, ori_code, ucode);
               if (lc == EC_TRUNCATE) fin = true;
               else if (lc == EC_ERROR) { status = EC_ST_CONTAMINANT; break; }
               else emit = true;
@@ -399,10 +488,10 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
               if (ori_code >= 0) {
                 const uint64_t co = ec_sel4(counts, ori_code);
                 if (co > (uint64_t)P.min_count) {
-                  if (co >= (uint32_t)P.cutoff || (int)(int8_t)qual[ip] >= (int)(int8_t)P.qual_cutoff) {
+                  if (co >= (uint32_t)P.cutoff || (int)(int8_t)buf[rc.z + (uint32_t)ip] >= (int)(int8_t)P.qual_cutoff) {
                     emit = true; multi = false;
                   } else {
-                    const uint64_t sum = counts[0] + counts[1] + counts[2] + counts[3];
+                    const uint64_t sum = (uint64_t)counts[0] + counts[1] + counts[2] + counts[3];
                     bool keep;
                     if (P.ptab_stride) {
                       const uint64_t bit = co * (uint64_t)P.ptab_stride + sum;
@@ -423,21 +512,20 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
               if (multi) {  // several possible substitutions (error_correct_reads.cc:464-560)
                 int check_code = ori_code;
                 bool success = false;
-                uint64_t cont_counts[4] = {0, 0, 0, 0};
+                W cont_counts[4] = {0, 0, 0, 0};
                 uint32_t cwcb = 0;  // continue_with_correct_base, one bit per code
-                int read_nbase_code = -1;
-                if (ip + d != end) read_nbase_code = qh_code(seq[ip + d]);
+                const int read_nbase_code = ip + d != end ? qh_code(nbase) : -1;
 #pragma unroll 1
                 for (int i = 0; i < 4; ++i) {
-                  const uint64_t ci = ec_sel4(counts, i);
-                  if (ci <= (uint64_t)P.min_count) continue;
+                  const W ci = ec_sel4(counts, i);
+                  if ((uint64_t)ci <= (uint64_t)P.min_count) continue;
                   check_code = i;
                   ec_mer nmer = mer;
-                  ec_dreplace0(nmer, k, d, i);
-                  ec_dshift(nmer, k, kmask, d, 0);
-                  uint64_t ncounts[4];
+                  ec_replace0(nmer, k, (uint32_t)(d > 0 ? i : 3 - i));
+                  ec_shift(nmer, k, km, d > 0 ? 0u : 3u);
+                  W ncounts[4];
                   int nucode = 0, nlevel;
-                  const int ncount = ec_best_alternatives(P.g, P.table, nmer, d, ncounts, &nucode, &nlevel);
+                  const int ncount = ec_best_alternatives<NARROW>(P.g, P.table, nmer, d, ncounts, &nucode, &nlevel);
                   if (ncount > 0 && nlevel >= level) {
                     if (read_nbase_code >= 0 && ec_sel4(ncounts, read_nbase_code) > 0) cwcb |= 1u << i;
                     success = true;
@@ -473,7 +561,7 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
                   }
                   if (ncand != 1) check_code = -1;
                   if (check_code >= 0) {
-                    const int lc = ec_log_substitution(P, mer, d, out, log, cpos, ori_code, check_code);
+                    const int lc = ec_log_substitution<NARROW>(P, mer, d, out, log, cpos, ori_code, check_code);
                     if (lc == EC_TRUNCATE) fin = true;
                     else if (lc == EC_ERROR) { status = EC_ST_CONTAMINANT; break; }
                   }
@@ -489,7 +577,11 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
               }
             }
           }
-          if (emit) { o[out] = (uint8_t)names[ec_dcode0(mer, k, d)]; out += d; }
+          if (emit) {  // *out++ = mer.base(0)
+            const uint32_t c0 = ec_code0(mer);
+            o[out] = (uint8_t)names[d > 0 ? c0 : 3u - c0];
+            out += d;
+          }
           ip += d;
         }
         if (fin) {
@@ -500,9 +592,10 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
             boff = log_off + nf + 1;  // one word left free: homo_trim may append a truncation to the forward log
             log.e = logs + boff;
             log.n = 0; log.lwin = 0; log.d = -1;
-            mer = anchor_mer;
+            mer.a0 = anchor_mer.b0; mer.a1 = anchor_mer.b1; mer.b0 = anchor_mer.a0; mer.b1 = anchor_mer.a1;
             ip = start_off - k - 1; pos = ip; end = -1; out = ip;
             prev_count = prev0;
+            nbase = ip != end ? seq[ip] : (uint8_t)0;
           } else {
             start_out = out + 1;
             nb = log.n;
@@ -512,6 +605,7 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
       }
     }
 
+    uint32_t* __restrict__ lg = logs + log_off;
     // ---- homo_trim (error_correct_reads.cc:567-597)
     if (status == EC_ST_OK && P.do_homo_trim) {
       int max_homo_score = INT_MIN, max_pos = INT_MIN, homo_score = 0;
@@ -714,6 +808,8 @@ struct qh_corrector {
   qh_query* contaminant = nullptr;
   qh_correct_params params;
   qh_ec_dev P;
+  qh_ec_dev* d_P = nullptr;    // the same block in device memory (the kernel reads it through the scalar cache)
+  bool narrow = false;         // value and tag fields fit 32 bits: the 32-bit kernel
   uint32_t* d_ptab = nullptr;
   // chunk state
   uint8_t* d_chunk = nullptr;  size_t chunk_cap = 0;   // staging of host-fed chunks
@@ -755,7 +851,7 @@ extern "C" void qh_corrector_destroy(qh_corrector* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* dptrs[] = {c->d_ptab, c->d_chunk, c->d_recs, c->d_hdr, c->d_tiles, c->d_nlplane, c->d_obuf, c->d_logs,
+  void* dptrs[] = {c->d_P, c->d_ptab, c->d_chunk, c->d_recs, c->d_hdr, c->d_tiles, c->d_nlplane, c->d_obuf, c->d_logs,
                    c->d_res, c->d_bsums, c->d_fa, c->d_log, c->d_meta, c->d_tot};
   for (void* p : dptrs) if (p) (void)hipFree(p);
   void* hptrs[] = {c->h_fa, c->h_log, c->h_meta, c->h_tot};
@@ -792,6 +888,11 @@ static int corrector_init(qh_corrector* c) {
     c->P.ptab_stride = (int)stride;
     c->P.ptab = c->d_ptab;
   }
+  const qh_geom& g = c->P.g;
+  const qh_geom& cg = c->P.cg;
+  c->narrow = g.vbits <= 32 && g.rbits + g.pbits <= 32 && (!c->P.ctable || (cg.vbits <= 32 && cg.rbits + cg.pbits <= 32));
+  QH_HIP(hipMalloc((void**)&c->d_P, sizeof(qh_ec_dev)));
+  QH_HIP(hipMemcpy(c->d_P, &c->P, sizeof(qh_ec_dev), hipMemcpyHostToDevice));
   return QH_OK;
 }
 
@@ -854,8 +955,12 @@ static int enqueue_correct(qh_corrector* c, const uint8_t* dev_buf, size_t len, 
   unsigned grid = (rec_cap + EC_BLOCK - 1) / EC_BLOCK;
   if (grid > 256u * 16u) grid = 256u * 16u;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(k_correct_reads, dim3(grid), dim3(EC_BLOCK), 0, c->stream, dev_buf, c->d_recs, d_hdr, c->d_meta, c->P,
-                     c->d_obuf, c->d_logs, c->d_res, c->d_tot);
+  if (c->narrow)
+    hipLaunchKernelGGL(k_correct_reads<true>, dim3(grid), dim3(EC_BLOCK), 0, c->stream, dev_buf, c->d_recs, d_hdr, c->d_meta,
+                       c->d_P, c->d_obuf, c->d_logs, c->d_res, c->d_tot);
+  else
+    hipLaunchKernelGGL(k_correct_reads<false>, dim3(grid), dim3(EC_BLOCK), 0, c->stream, dev_buf, c->d_recs, d_hdr, c->d_meta,
+                       c->d_P, c->d_obuf, c->d_logs, c->d_res, c->d_tot);
   QH_HIP(hipEventRecord(c->ev[2], c->stream));
   hipLaunchKernelGGL(k_ec_block_sums, dim3(nblocks ? nblocks : 1), dim3(EC_FMT_BLOCK), 0, c->stream, c->d_res, c->d_meta,
                      c->d_bsums);
