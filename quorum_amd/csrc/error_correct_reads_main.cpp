@@ -1,0 +1,316 @@
+// quorum_error_correct_reads -- drop-in command line of Quorum's read corrector on top of
+// libquorum_hip.
+//
+// Mirrors main of src/error_correct_reads.cc:676-742 and the switch set of
+// src/error_correct_reads_cmdline.yaggo:6-71: -t/--thread (=1), -m/--min-count (=1), -s/--skip (=1),
+// -g/--good (=2), -a/--anchor-count (=3), -w/--window (=10), -e/--error (=3), -o/--output prefix,
+// --contaminant path, --trim-contaminant, --homo-trim int32, --gzip, -M/--no-mmap,
+// --apriori-error-rate (=0.01), --poisson-threshold (=1e-6), -p/--cutoff, -q/--qual-cutoff-value,
+// -Q/--qual-cutoff-char (conflict), -d/--no-discard, -v/--verbose; positional: db, sequence+.
+// Output: <prefix>.fa and <prefix>.log, or stdout / stderr when -o is not given (:160-161,:723).
+// Differences from upstream: -t is accepted and ignored (the GPU supplies the parallelism; reads keep
+// their input order, as upstream with -t 1); --contaminant takes the FASTA file itself (upstream takes a
+// `jellyfish count -C` dump of it, Makefile.am:54-55); --gzip is refused (no zlib stream here);
+// --gpu N selects the HIP device.
+#include <errno.h>
+#include <fcntl.h>
+#include <limits.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "../../include/quorum_hip.h"
+
+static const char* kUsage = "Usage: error_correct_reads [options] db:path sequence:path+";
+
+static const char* kHelp =
+    "Error correct reads from a fastq file based on the k-mer frequencies.\n\n"
+    "Options (default value in (), *required):\n"
+    " -t, --thread=uint32                      Number of threads (1)\n"
+    " -m, --min-count=uint32                   Minimum count for a k-mer to be considered \"good\" (1)\n"
+    " -s, --skip=uint32                        Number of bases to skip for start k-mer (1)\n"
+    " -g, --good=uint32                        Number of good k-mer in a row for anchor (2)\n"
+    " -a, --anchor-count=uint32                Minimum count for an anchor k-mer (3)\n"
+    " -w, --window=uint32                      Size of window (10)\n"
+    " -e, --error=uint32                       Maximum number of error in a window (3)\n"
+    " -o, --output=prefix                      Output file prefix (error_corrected)\n"
+    "     --contaminant=path                   FASTA file of contaminant sequences\n"
+    "     --trim-contaminant                   Trim reads containing contaminated k-mers instead of discarding (false)\n"
+    "     --homo-trim=int32                    Trim homo-polymer run at the 3' end\n"
+    "     --gzip                               Gzip output file (not supported)\n"
+    " -M, --no-mmap                            Do not memory map the input mer database (false)\n"
+    "     --apriori-error-rate=double          Probability of a base being an error (0.01)\n"
+    "     --poisson-threshold=double           Error probability threshold in Poisson test (1e-6)\n"
+    " -p, --cutoff=uint32                      Poisson cutoff when there are multiple choices\n"
+    " -q, --qual-cutoff-value=uint32           Any base above with quality equal or greater is untouched when there are multiple choices\n"
+    " -Q, --qual-cutoff-char=string            Any base above with quality equal or greater is untouched when there are multiple choices\n"
+    " -d, --no-discard                         Do not discard reads, output a single N (false)\n"
+    " -v, --verbose                            Be verbose (false)\n"
+    "     --gpu=int                            HIP device (0)\n"
+    " -U, --usage                              Usage\n"
+    " -h, --help                               This message\n"
+    " -V, --version                            Version";
+
+[[noreturn]] static void error(const std::string& msg) {
+  fprintf(stderr, "Error: %s\n%s\nUse --help for more information\n", msg.c_str(), kUsage);
+  exit(EXIT_FAILURE);
+}
+
+[[noreturn]] static void die(const std::string& msg) {  // err::die
+  fprintf(stderr, "%s\n", msg.c_str());
+  exit(EXIT_FAILURE);
+}
+
+static uint32_t conv_u32(const char* s) {
+  if (!s || !*s || *s == '-') error(std::string("Invalid conversion of '") + (s ? s : "") + "' to uint32_t");
+  errno = 0;
+  char* end = nullptr;
+  unsigned long long v = strtoull(s, &end, 0);
+  if (errno || end == s || *end || v > UINT32_MAX) error(std::string("Invalid conversion of '") + s + "' to uint32_t");
+  return (uint32_t)v;
+}
+static int32_t conv_i32(const char* s) {
+  errno = 0;
+  char* end = nullptr;
+  long v = strtol(s ? s : "", &end, 0);
+  if (!s || errno || end == s || *end || v < INT32_MIN || v > INT32_MAX) error(std::string("Invalid conversion of '") + (s ? s : "") + "' to int32_t");
+  return (int32_t)v;
+}
+static double conv_double(const char* s) {
+  errno = 0;
+  char* end = nullptr;
+  double v = strtod(s ? s : "", &end);
+  if (!s || errno || end == s || *end) error(std::string("Invalid conversion of '") + (s ? s : "") + "' to double_t");
+  return v;
+}
+
+struct args_t {
+  uint32_t thread = 1, min_count = 1, skip = 1, good = 2, anchor_count = 3, window = 10, error = 3;
+  std::string output = "error_corrected"; bool output_given = false;
+  const char* contaminant = nullptr;
+  bool trim_contaminant = false, gzip = false, no_mmap = false, no_discard = false, verbose = false;
+  int32_t homo_trim = 0; bool homo_trim_given = false;
+  double apriori_error_rate = 0.01, poisson_threshold = 1e-6;
+  uint32_t cutoff = 0; bool cutoff_given = false;
+  uint32_t qual_cutoff_value = 0; bool qual_cutoff_value_given = false;
+  std::string qual_cutoff_char; bool qual_cutoff_char_given = false;
+  int gpu = 0;
+  const char* db = nullptr;
+  std::vector<const char*> sequence;
+};
+
+static void parse(int argc, char** argv, args_t& a) {
+  struct opt { char s; const char* l; bool has_arg; };
+  // keys without a short form use control characters
+  static const opt opts[] = {
+      {'t', "thread", true}, {'m', "min-count", true}, {'s', "skip", true}, {'g', "good", true},
+      {'a', "anchor-count", true}, {'w', "window", true}, {'e', "error", true}, {'o', "output", true},
+      {1, "contaminant", true}, {2, "trim-contaminant", false}, {3, "homo-trim", true}, {4, "gzip", false},
+      {'M', "no-mmap", false}, {5, "apriori-error-rate", true}, {6, "poisson-threshold", true},
+      {'p', "cutoff", true}, {'q', "qual-cutoff-value", true}, {'Q', "qual-cutoff-char", true},
+      {'d', "no-discard", false}, {'v', "verbose", false}, {7, "gpu", true}};
+  std::vector<const char*> pos;
+  bool only_pos = false;
+  for (int i = 1; i < argc; ++i) {
+    const char* s = argv[i];
+    if (only_pos || s[0] != '-' || s[1] == 0) { pos.push_back(s); continue; }
+    if (!strcmp(s, "--")) { only_pos = true; continue; }
+    if (!strcmp(s, "-h") || !strcmp(s, "--help")) { printf("%s\n\n%s\n", kUsage, kHelp); exit(0); }
+    if (!strcmp(s, "-U") || !strcmp(s, "--usage")) { printf("%s\n", kUsage); exit(0); }
+    if (!strcmp(s, "-V") || !strcmp(s, "--version")) { printf("%s\n", qh_version()); exit(0); }
+    const opt* o = nullptr;
+    const char* val = nullptr;
+    if (s[1] == '-') {
+      const char* eq = strchr(s + 2, '=');
+      const std::string name(s + 2, eq ? (size_t)(eq - s - 2) : strlen(s + 2));
+      for (auto& x : opts) if (name == x.l) o = &x;
+      if (!o) error(std::string("unrecognized option '") + s + "'");
+      val = eq ? eq + 1 : nullptr;
+      if (!o->has_arg && val) error(std::string("option '--") + o->l + "' doesn't allow an argument");
+    } else {
+      for (auto& x : opts) if (s[1] == x.s && x.s > 7) o = &x;
+      if (!o) error(std::string("invalid option -- '") + s[1] + "'");
+      if (o->has_arg) val = s[2] ? s + 2 : nullptr;
+      else if (s[2]) error(std::string("invalid option -- '") + s[2] + "'");
+    }
+    if (o->has_arg && !val) {
+      if (i + 1 >= argc) error(std::string("option '") + s + "' requires an argument");
+      val = argv[++i];
+    }
+    switch (o->s) {
+      case 't': a.thread = conv_u32(val); break;
+      case 'm': a.min_count = conv_u32(val); break;
+      case 's': a.skip = conv_u32(val); break;
+      case 'g': a.good = conv_u32(val); break;
+      case 'a': a.anchor_count = conv_u32(val); break;
+      case 'w': a.window = conv_u32(val); break;
+      case 'e': a.error = conv_u32(val); break;
+      case 'o': a.output = val; a.output_given = true; break;
+      case 1: a.contaminant = val; break;
+      case 2: a.trim_contaminant = true; break;
+      case 3: a.homo_trim = conv_i32(val); a.homo_trim_given = true; break;
+      case 4: a.gzip = true; break;
+      case 'M': a.no_mmap = true; break;
+      case 5: a.apriori_error_rate = conv_double(val); break;
+      case 6: a.poisson_threshold = conv_double(val); break;
+      case 'p': a.cutoff = conv_u32(val); a.cutoff_given = true; break;
+      case 'q': a.qual_cutoff_value = conv_u32(val); a.qual_cutoff_value_given = true; break;
+      case 'Q': a.qual_cutoff_char = val; a.qual_cutoff_char_given = true; break;
+      case 'd': a.no_discard = true; break;
+      case 'v': a.verbose = true; break;
+      case 7: a.gpu = (int)conv_u32(val); break;
+    }
+  }
+  if (a.qual_cutoff_value_given && a.qual_cutoff_char_given)
+    error("Switches [-Q, --qual-cutoff-char=string] and [-q, --qual-cutoff-value=uint32] are mutually exclusive");
+  if (pos.size() < 2) error("Requires at least 2 arguments.");
+  a.db = pos[0];
+  a.sequence.assign(pos.begin() + 1, pos.end());
+}
+
+static void write_all(int fd, const char* p, size_t n, const std::string& name) {
+  while (n) {
+    ssize_t w = write(fd, p, n);
+    if (w < 0) { if (errno == EINTR) continue; die("Failed to write to file '" + name + "': " + strerror(errno)); }
+    p += w; n -= (size_t)w;
+  }
+}
+
+static size_t read_some(int fd, char* dst, size_t n) {
+  size_t got = 0;
+  while (got < n) {
+    ssize_t r = read(fd, dst + got, n - got);
+    if (r < 0) { if (errno == EINTR) continue; die(std::string("read error: ") + strerror(errno)); }
+    if (r == 0) break;
+    got += (size_t)r;
+  }
+  return got;
+}
+
+int main(int argc, char* argv[]) {
+  args_t args;
+  parse(argc, argv, args);
+  // src/error_correct_reads.cc:680-685
+  if (args.qual_cutoff_char_given && args.qual_cutoff_char.size() != 1)
+    error("The qual-cutoff-char must be one ASCII character.");
+  if (args.qual_cutoff_value_given && args.qual_cutoff_value > (uint32_t)CHAR_MAX)
+    error("The qual-cutoff-value must be in the range 0-127.");
+  const char qual_cutoff = args.qual_cutoff_char_given ? args.qual_cutoff_char[0]
+                           : (args.qual_cutoff_value_given ? (char)args.qual_cutoff_value : (char)CHAR_MAX);
+  if (args.gzip) error("--gzip is not supported by this build: pipe the .fa output through gzip");
+
+  const auto t_start = std::chrono::steady_clock::now();
+  auto secs = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
+  auto vlog = [&](const std::string& m) { if (args.verbose) fprintf(stderr, "[%.3f] %s\n", secs(), m.c_str()); };
+
+  vlog("Loading mer database");  // :688-690
+  qh_query* db = nullptr;
+  if (qh_query_open(&db, args.db, args.gpu) != QH_OK) die(qh_last_error());
+  int k = 0, bits = 0;
+  uint64_t size = 0;
+  qh_query_info(db, &k, &bits, &size);
+
+  qh_query* contaminant = nullptr;  // :692-708
+  if (args.contaminant) {
+    vlog("Loading contaminant sequences");
+    if (qh_contaminant_open_fasta(&contaminant, args.contaminant, k, args.gpu) != QH_OK) die(qh_last_error());
+  }
+
+  unsigned cutoff = args.cutoff;  // :712-718
+  if (!args.cutoff_given) {
+    vlog("Computing Poisson cutoff");
+    if (qh_query_poisson_cutoff(db, args.apriori_error_rate / 3, args.poisson_threshold / args.apriori_error_rate, &cutoff) != QH_OK)
+      die(qh_last_error());
+  }
+  vlog("Using cutoff of " + std::to_string(cutoff));
+  if (cutoff == 0 && !args.cutoff_given) die("Cutoff computation failed. Pass it explicitly with -p switch.");
+
+  qh_correct_params p;  // :720-736
+  memset(&p, 0, sizeof p);
+  p.skip = (int32_t)args.skip; p.good = (int32_t)args.good; p.anchor = (int32_t)args.anchor_count;
+  p.min_count = (int32_t)args.min_count; p.cutoff = (int32_t)cutoff; p.window = (int32_t)args.window;
+  p.error = (int32_t)args.error; p.qual_cutoff = (int32_t)qual_cutoff; p.trim_contaminant = args.trim_contaminant;
+  p.do_homo_trim = args.homo_trim_given; p.homo_trim = args.homo_trim; p.no_discard = args.no_discard;
+  p.collision_prob = args.apriori_error_rate / 3; p.poisson_threshold = args.poisson_threshold;
+  qh_corrector* ec = nullptr;
+  if (qh_corrector_create(&ec, db, contaminant, &p) != QH_OK) die(qh_last_error());
+
+  // open_file (:134-155): <prefix>.log / <prefix>.fa, or stderr / stdout without a prefix
+  const std::string prefix = args.output_given ? args.output : "";
+  const std::string log_name = prefix.empty() ? "/dev/fd/2" : prefix + ".log";
+  const std::string fa_name = prefix.empty() ? "/dev/fd/1" : prefix + ".fa";
+  const int log_fd = prefix.empty() ? 2 : open(log_name.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+  if (log_fd < 0) die("Failed to open file '" + log_name + "': " + strerror(errno));
+  const int fa_fd = prefix.empty() ? 1 : open(fa_name.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+  if (fa_fd < 0) die("Failed to open file '" + fa_name + "': " + strerror(errno));
+
+  vlog("Correcting reads");
+  const char* cb = getenv("QUORUM_HIP_CHUNK_MB");
+  const size_t chunk_bytes = (cb && atol(cb) > 0 ? (size_t)atol(cb) : 256) << 20;
+  char* buf = nullptr;
+  size_t cap = chunk_bytes;
+  bool pinned = qh_host_alloc((void**)&buf, cap) == QH_OK;
+  if (!pinned) buf = (char*)malloc(cap);
+  if (!buf) die("out of memory for the chunk buffer");
+  qh_correct_stats total;
+  memset(&total, 0, sizeof total);
+  for (const char* path : args.sequence) {
+    const int fd = !strcmp(path, "-") || !strcmp(path, "/dev/fd/0") ? 0 : open(path, O_RDONLY);
+    if (fd < 0) die(std::string("Can't open file '") + path + "'");
+    size_t have = 0;
+    bool eof = false;
+    while (!eof || have) {
+      if (!eof && have < cap) {
+        const size_t want = cap - have, r = read_some(fd, buf + have, want);
+        have += r;
+        if (r < want) eof = true;
+      }
+      if (have == 0) break;
+      size_t used = 0;
+      if (qh_corrector_correct_fastq(ec, buf, have, eof, &used) != QH_OK) die(qh_last_error());
+      const char *fa, *lg;
+      size_t nfa, nlg;
+      qh_correct_stats st;
+      if (qh_corrector_fetch(ec, &fa, &nfa, &lg, &nlg, &st) != QH_OK) die(qh_last_error());
+      write_all(fa_fd, fa, nfa, fa_name);
+      write_all(log_fd, lg, nlg, log_name);
+      total.reads += st.reads; total.corrected += st.corrected; total.skipped += st.skipped;
+      total.substitutions += st.substitutions; total.truncations += st.truncations;
+      total.bases_in += st.bases_in; total.bases_out += st.bases_out;
+      if (used == 0) {
+        if (eof) die(std::string("Truncated fastq file '") + path + "'");
+        // a record longer than the buffer: grow it
+        char* nb = nullptr;
+        const size_t ncap = cap * 2;
+        bool npinned = qh_host_alloc((void**)&nb, ncap) == QH_OK;
+        if (!npinned) nb = (char*)malloc(ncap);
+        if (!nb) die("out of memory for the chunk buffer");
+        memcpy(nb, buf, have);
+        if (pinned) qh_host_free(buf); else free(buf);
+        buf = nb; cap = ncap; pinned = npinned;
+        continue;
+      }
+      memmove(buf, buf + used, have - used);
+      have -= used;
+    }
+    if (fd != 0) close(fd);
+  }
+  if (args.verbose)
+    fprintf(stderr, "[%.3f] Done: reads %llu corrected %llu skipped %llu substitutions %llu truncations %llu bases %llu -> %llu\n",
+            secs(), (unsigned long long)total.reads, (unsigned long long)total.corrected, (unsigned long long)total.skipped,
+            (unsigned long long)total.substitutions, (unsigned long long)total.truncations,
+            (unsigned long long)total.bases_in, (unsigned long long)total.bases_out);
+  if (fa_fd > 2) close(fa_fd);
+  if (log_fd > 2) close(log_fd);
+  if (pinned) qh_host_free(buf); else free(buf);
+  qh_corrector_destroy(ec);
+  if (contaminant) qh_query_close(contaminant);
+  qh_query_close(db);
+  return 0;
+}

@@ -103,13 +103,16 @@ template <> struct ec_word<true> { typedef uint32_t type; };
 template <> struct ec_word<false> { typedef uint64_t type; };
 
 // database_query::operator[] for N hashed mers at once. Probing is linear inside a 2^wbits-slot
-// window, so consecutive probes are consecutive words: every round loads the 32-byte group of four
+// window, so consecutive probes are consecutive words: every round loads the 64-byte line of eight
 // slots that holds the next probes of each unresolved lookup, and all N lookups advance in the same
 // round. What bounds a read is the number of dependent memory round trips per base; three of the four
-// alternatives of get_best_alternatives are normally ABSENT, and an unsuccessful search at load 0.54
-// walks 2.9 slots on average with a long tail, of which the wave pays the maximum over its 64 lanes.
-// One slot per round and one lookup after the other cost about 60 round trips per base; this form 3-4.
-struct ec_group { uint64_t a, b, c, d; };
+// alternatives of get_best_alternatives are normally ABSENT, and an unsuccessful search at load 0.55
+// walks 2.9 slots on average with a long tail, of which the wave pays the maximum over its 64 lanes
+// x 4 lookups. One slot per round and one lookup after the other cost about 60 round trips per base;
+// four slots per round 6.6 (simulated maximum over a wave), eight slots per round 3.9. A line is the
+// unit HBM delivers anyway, so the wider rounds add no memory traffic.
+#define EC_GROUP 8
+struct ec_group { uint64_t s[EC_GROUP]; };
 
 template <int N, bool NARROW>
 __device__ __forceinline__ void ec_lookup_wide(const qh_geom& g, const uint64_t* __restrict__ table,
@@ -128,8 +131,8 @@ __device__ __forceinline__ void ec_lookup_wide(const qh_geom& g, const uint64_t*
     pend[n] = p.shard == (uint32_t)g.shard_id;
     const uint32_t ho = (uint32_t)p.home & wmask;
     tag0[n] = (W)p.tag0;
-    gaddr[n] = p.home & ~(uint64_t)3;
-    pi[n] = -(int)(ho & 3u);
+    gaddr[n] = p.home & ~(uint64_t)(EC_GROUP - 1);
+    pi[n] = -(int)(ho & (uint32_t)(EC_GROUP - 1));
     if (pend[n]) grp[n] = *reinterpret_cast<const ec_group*>(table + gaddr[n]);
   }
   for (;;) {
@@ -137,18 +140,18 @@ __device__ __forceinline__ void ec_lookup_wide(const qh_geom& g, const uint64_t*
 #pragma unroll
     for (int n = 0; n < N; ++n) {
       if (!pend[n]) continue;
-      const uint64_t s4[4] = {grp[n].a, grp[n].b, grp[n].c, grp[n].d};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < EC_GROUP; ++j) {
         const int idx = pi[n] + j;
+        const uint64_t sj = grp[n].s[j];
         if (pend[n] && idx >= 0) {
-          if (idx > g.max_reprobe || s4[j] == 0) pend[n] = false;
-          else if ((W)(s4[j] >> g.vbits) == (tag0[n] | (W)(idx + 1))) { v[n] = (W)s4[j] & (W)g.vmask; pend[n] = false; }
+          if (idx > g.max_reprobe || sj == 0) pend[n] = false;
+          else if ((W)(sj >> g.vbits) == (tag0[n] | (W)(idx + 1))) { v[n] = (W)sj & (W)g.vmask; pend[n] = false; }
         }
       }
       if (pend[n]) {  // next group of the window (wraps at the window's end)
-        gaddr[n] = (gaddr[n] & ~(uint64_t)wmask) | (((uint32_t)gaddr[n] + 4u) & wmask);
-        pi[n] += 4;
+        gaddr[n] = (gaddr[n] & ~(uint64_t)wmask) | (((uint32_t)gaddr[n] + (uint32_t)EC_GROUP) & wmask);
+        pi[n] += EC_GROUP;
         any = true;
       }
     }
@@ -159,7 +162,7 @@ __device__ __forceinline__ void ec_lookup_wide(const qh_geom& g, const uint64_t*
   }
 }
 
-// tables of fewer than four slots per window: one slot at a time
+// tables of fewer than EC_GROUP slots per window: one slot at a time
 __device__ __forceinline__ uint64_t ec_lookup_narrow_table(const qh_geom& g, const uint64_t* __restrict__ table, uint64_t h) {
   const qh_pos p = qh_locate_hash(g, h);
   if (p.shard != (uint32_t)g.shard_id) return 0;
@@ -177,7 +180,7 @@ template <bool NARROW>
 __device__ __forceinline__ typename ec_word<NARROW>::type ec_lookup(const qh_geom& g, const uint64_t* __restrict__ table,
                                                                      uint64_t h) {
   typedef typename ec_word<NARROW>::type W;
-  if (g.wbits < 2) return (W)ec_lookup_narrow_table(g, table, h);
+  if (g.wbits < 3) return (W)ec_lookup_narrow_table(g, table, h);
   const uint64_t hh[1] = {h};
   W v[1];
   ec_lookup_wide<1, NARROW>(g, table, hh, v);
@@ -201,7 +204,7 @@ __device__ __forceinline__ int ec_best_alternatives(const qh_geom& g, const uint
     ec_replace0(a, k, (uint32_t)y);
     h[y] = ec_hash(a, k);
   }
-  if (g.wbits < 2) {
+  if (g.wbits < 3) {
 #pragma unroll
     for (int y = 0; y < 4; ++y) w[y] = (W)ec_lookup_narrow_table(g, table, h[y]);
   } else {
@@ -330,8 +333,9 @@ __device__ __forceinline__ uint32_t ec_error_text_bytes(uint32_t status) {
 
 // check_contaminant (error_correct_reads.cc:346-357)
 template <bool NARROW>
-__device__ __forceinline__ int ec_check_contaminant(const qh_ec_dev& P, const ec_mer& m, ec_log& log, int cpos) {
-  if (P.ctable && ec_lookup<NARROW>(P.cg, P.ctable, ec_hash(m, P.g.k)) != 0) {
+__device__ __forceinline__ int ec_check_contaminant(const qh_ec_dev& P, const uint64_t* __restrict__ ctable, const ec_mer& m,
+                                                    ec_log& log, int cpos) {
+  if (ctable && ec_lookup<NARROW>(P.cg, ctable, ec_hash(m, P.g.k)) != 0) {
     if (P.trim_contaminant) { ec_truncation(log, cpos, P.window, P.error); return EC_TRUNCATE; }
     return EC_ERROR;
   }
@@ -340,11 +344,11 @@ __device__ __forceinline__ int ec_check_contaminant(const qh_ec_dev& P, const ec
 
 // log_substitution (error_correct_reads.cc:360-379); from / to are codes of the forward strand
 template <bool NARROW>
-__device__ __forceinline__ int ec_log_substitution(const qh_ec_dev& P, ec_mer& m, int d, int& out, ec_log& log,
-                                                   int cpos, int from, int to) {
+__device__ __forceinline__ int ec_log_substitution(const qh_ec_dev& P, const uint64_t* __restrict__ ctable, ec_mer& m, int d,
+                                                   int& out, ec_log& log, int cpos, int from, int to) {
   if (from == to) return EC_OK;
   ec_replace0(m, P.g.k, (uint32_t)(d > 0 ? to : 3 - to));
-  const int cc = ec_check_contaminant<NARROW>(P, m, log, cpos);
+  const int cc = ec_check_contaminant<NARROW>(P, ctable, m, log, cpos);
   if (cc != EC_OK) return cc;
   const uint32_t entry = (uint32_t)cpos | ((uint32_t)(from >= 0 ? from : 4) << 25) | ((uint32_t)(to >= 0 ? to : 4) << 28);
   if (ec_push(log, entry, P.window, P.error)) {
@@ -369,6 +373,9 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
                                                             const uint2* __restrict__ hdr,
                                                             const qh_meta* __restrict__ meta,
                                                             const qh_ec_dev* __restrict__ Pp,
+                                                            const uint64_t* __restrict__ table,
+                                                            const uint64_t* __restrict__ ctable,
+                                                            const uint32_t* __restrict__ ptab,
                                                             uint8_t* __restrict__ obuf, uint32_t* __restrict__ logs,
                                                             uint32_t* __restrict__ res,
                                                             qh_ec_totals* __restrict__ tot) {
@@ -415,10 +422,10 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
       int found = 0;
       while (in < len) {
         const uint64_t h = ec_hash(mer, k);
-        const bool contaminated = P.ctable && ec_lookup<NARROW>(P.cg, P.ctable, h) != 0;
+        const bool contaminated = ctable && ec_lookup<NARROW>(P.cg, ctable, h) != 0;
         if (contaminated && !P.trim_contaminant) { status = EC_ST_CONTAMINANT; break; }
         if (!contaminated) {
-          const W v = ec_lookup<NARROW>(P.g, P.table, h);
+          const W v = ec_lookup<NARROW>(P.g, table, h);
           const W val = (v & 1) ? v >> 1 : 0;  // get_val
           found = (int)val >= P.anchor ? found + 1 : 0;
           if (found >= P.good) { anchored = true; break; }
@@ -441,7 +448,7 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
       const int start_off = in;
       uint32_t prev0;
       {
-        const W v = ec_lookup<NARROW>(P.g, P.table, ec_hash(mer, k));
+        const W v = ec_lookup<NARROW>(P.g, table, ec_hash(mer, k));
         prev0 = (uint32_t)((v & 1) ? v >> 1 : 0);
       }
       int d = +1;
@@ -462,15 +469,15 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
           const uint32_t x = ori_code >= 0 ? (uint32_t)ori_code : 0u;
           ec_shift(mer, k, km, d > 0 ? x : 3u - x);
           bool emit = false;
-          if (ori_code >= 0 && P.ctable) {
-            const int cc = ec_check_contaminant<NARROW>(P, mer, log, cpos);
+          if (ori_code >= 0 && ctable) {
+            const int cc = ec_check_contaminant<NARROW>(P, ctable, mer, log, cpos);
             if (cc == EC_TRUNCATE) fin = true;
             else if (cc == EC_ERROR) { status = EC_ST_CONTAMINANT; break; }
           }
           if (!fin) {
             W counts[4];
             int ucode = 0, level;
-            const int count = ec_best_alternatives<NARROW>(P.g, P.table, mer, d, counts, &ucode, &level);
+            const int count = ec_best_alternatives<NARROW>(P.g, table, mer, d, counts, &ucode, &level);
             if (count == 1 && ucode == ori_code) {  // the read's base is the one continuation: the common case
               prev_count = (uint32_t)ec_sel4(counts, ucode);
               emit = true;
@@ -479,7 +486,7 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
               fin = true;
             } else if (count == 1) {  // one continuation: a substitution
               prev_count = (uint32_t)ec_sel4(counts, ucode);
-              const int lc = ec_log_substitution<NARROW>(P, mer, d, out, log, cpos, ori_code, ucode);
+              const int lc = ec_log_substitution<NARROW>(P, ctable, mer, d, out, log, cpos, ori_code, ucode);
               if (lc == EC_TRUNCATE) fin = true;
               else if (lc == EC_ERROR) { status = EC_ST_CONTAMINANT; break; }
               else emit = true;
@@ -495,7 +502,7 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
                     bool keep;
                     if (P.ptab_stride) {
                       const uint64_t bit = co * (uint64_t)P.ptab_stride + sum;
-                      keep = (P.ptab[bit >> 5] >> (bit & 31)) & 1u;
+                      keep = (ptab[bit >> 5] >> (bit & 31)) & 1u;
                     } else {
                       keep = ec_poisson_term((double)sum * P.collision_prob, (unsigned)co) < P.poisson_threshold;
                     }
@@ -525,7 +532,7 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
                   ec_shift(nmer, k, km, d > 0 ? 0u : 3u);
                   W ncounts[4];
                   int nucode = 0, nlevel;
-                  const int ncount = ec_best_alternatives<NARROW>(P.g, P.table, nmer, d, ncounts, &nucode, &nlevel);
+                  const int ncount = ec_best_alternatives<NARROW>(P.g, table, nmer, d, ncounts, &nucode, &nlevel);
                   if (ncount > 0 && nlevel >= level) {
                     if (read_nbase_code >= 0 && ec_sel4(ncounts, read_nbase_code) > 0) cwcb |= 1u << i;
                     success = true;
@@ -561,7 +568,7 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
                   }
                   if (ncand != 1) check_code = -1;
                   if (check_code >= 0) {
-                    const int lc = ec_log_substitution<NARROW>(P, mer, d, out, log, cpos, ori_code, check_code);
+                    const int lc = ec_log_substitution<NARROW>(P, ctable, mer, d, out, log, cpos, ori_code, check_code);
                     if (lc == EC_TRUNCATE) fin = true;
                     else if (lc == EC_ERROR) { status = EC_ST_CONTAMINANT; break; }
                   }
@@ -957,10 +964,10 @@ static int enqueue_correct(qh_corrector* c, const uint8_t* dev_buf, size_t len, 
   if (grid < 1) grid = 1;
   if (c->narrow)
     hipLaunchKernelGGL(k_correct_reads<true>, dim3(grid), dim3(EC_BLOCK), 0, c->stream, dev_buf, c->d_recs, d_hdr, c->d_meta,
-                       c->d_P, c->d_obuf, c->d_logs, c->d_res, c->d_tot);
+                       c->d_P, c->P.table, c->P.ctable, c->P.ptab, c->d_obuf, c->d_logs, c->d_res, c->d_tot);
   else
     hipLaunchKernelGGL(k_correct_reads<false>, dim3(grid), dim3(EC_BLOCK), 0, c->stream, dev_buf, c->d_recs, d_hdr, c->d_meta,
-                       c->d_P, c->d_obuf, c->d_logs, c->d_res, c->d_tot);
+                       c->d_P, c->P.table, c->P.ctable, c->P.ptab, c->d_obuf, c->d_logs, c->d_res, c->d_tot);
   QH_HIP(hipEventRecord(c->ev[2], c->stream));
   hipLaunchKernelGGL(k_ec_block_sums, dim3(nblocks ? nblocks : 1), dim3(EC_FMT_BLOCK), 0, c->stream, c->d_res, c->d_meta,
                      c->d_bsums);

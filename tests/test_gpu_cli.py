@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "quorum_amd", "bin")
+ADAPTERS = os.path.join(ROOT, "tests", "golden", "adapter.fa")
 
 
 def test_create_database_cli_end_to_end(tmp_path):
@@ -80,3 +81,62 @@ def test_cli_min_qual_char_and_missing_file(tmp_path):
     r = subprocess.run([os.path.join(BIN, "quorum_create_database"), "-s", "1k", "-m", "4", "-b", "7", "-q", "38",
                         "-o", out, str(tmp_path / "missing.fq")], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0
+
+
+def test_quorum_pipeline_cli_end_to_end(tmp_path):
+    """what the quorum driver runs (src/quorum.in:155-171): quorum_create_database, then
+    quorum_error_correct_reads on the same files with the database; .fa and .log against the oracle"""
+    k, bits = 24, 7
+    g = synth.make_genome(40000, seed=21)
+    fq1 = synth.make_fastq(g, 9000, 100, seed=22, tails=True).tobytes()
+    fq2 = synth.make_fastq(g, 5000, 120, err=0.02, seed=23, first_id=9000).tobytes()
+    recs = fq2.split(b"\n")
+    multi = []
+    for i in range(0, len(recs) - 1, 4):  # second file in multi-line form: the host parser inside the CLI
+        s, q = recs[i + 1], recs[i + 3]
+        multi += [recs[i], s[:70], s[70:], b"+", q[:70], q[70:]]
+    fq2m = b"\n".join(multi) + b"\n"
+    (tmp_path / "a.fastq").write_bytes(fq1)
+    (tmp_path / "b.fastq").write_bytes(fq2m)
+    dbf = str(tmp_path / "q_mer_database.jf")
+    env = dict(os.environ, QUORUM_HIP_CHUNK_MB="1")  # several chunks per file, records cut at chunk ends
+    r = subprocess.run([os.path.join(BIN, "quorum_create_database"), "-s", "1M", "-m", str(k), "-b", str(bits),
+                        "-q", "38", "-o", dbf, str(tmp_path / "a.fastq"), str(tmp_path / "b.fastq")],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    prefix = str(tmp_path / "q")
+    r = subprocess.run([os.path.join(BIN, "quorum_error_correct_reads"), "-t", "4", "--contaminant", ADAPTERS,
+                        "--trim-contaminant", "-d", "-v", dbf, "-o", prefix, str(tmp_path / "a.fastq"),
+                        str(tmp_path / "b.fastq")], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "Using cutoff of" in r.stderr
+    db = po.OracleDB(1 << 20, k, bits)
+    db.add_fastq(fq1, 38)
+    db.add_fastq(fq2, 38)
+    oc = po.OracleDB(1 << 16, k, 1)
+    oc.add_fasta(open(ADAPTERS, "rb").read())
+    cut = db.poisson_cutoff(0.01 / 3, 1e-6 / 0.01)
+    assert ("Using cutoff of %d" % cut) in r.stderr
+    par = po.ec_params(cut, trim_contaminant=True, no_discard=True)
+    fa1, lg1, n1 = db.correct_fastq(fq1, par, contaminant=oc)
+    fa2, lg2, n2 = db.correct_fastq(fq2m, par, contaminant=oc)
+    assert open(prefix + ".fa", "rb").read() == fa1 + fa2
+    assert open(prefix + ".log", "rb").read() == lg1 + lg2
+    assert ("reads %d " % (n1 + n2)) in r.stderr
+    # without -o the streams go to stdout / stderr (error_correct_reads.cc:160-161,723)
+    r = subprocess.run([os.path.join(BIN, "quorum_error_correct_reads"), "-p", str(cut), "-a", "200", dbf,
+                        str(tmp_path / "a.fastq")], capture_output=True, timeout=300, env=env)
+    assert r.returncode == 0
+    fa, lg, n = db.correct_fastq(fq1, po.ec_params(cut, anchor=200))
+    assert r.stdout == fa and r.stderr == lg and lg.count(b"Skipped") == 9000
+    # argument rules of main (:680-683) and of the switch parser
+    for argv, msg in ((["-Q", "ab", dbf, "x"], "must be one ASCII character"),
+                      (["-q", "200", dbf, "x"], "must be in the range 0-127"),
+                      (["-q", "40", "-Q", "I", dbf, "x"], "mutually exclusive"),
+                      ([dbf], "Requires at least 2 arguments"),
+                      (["--gzip", dbf, "x"], "not supported")):
+        r = subprocess.run([os.path.join(BIN, "quorum_error_correct_reads")] + argv, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 1 and msg in r.stderr, (argv, r.stderr)
+    r = subprocess.run([os.path.join(BIN, "quorum_error_correct_reads"), str(tmp_path / "missing.jf"), "x"],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1
