@@ -161,6 +161,12 @@ int qh_detect_min_qual_char(const char* buf, size_t len, int* min_q_char);
 int qh_host_alloc(void** out, size_t bytes);
 void qh_host_free(void* p);
 
+/* The library's position hash of 2-bit packed mers (host only): the owner shard of a mer is the low
+ * shard_bits of it, and the four mers that differ in their first or last base share its low 2k-4 bits.
+ * No upstream counterpart (Jellyfish's hash is a GF(2) matrix product); used by the multi-GPU driver
+ * and the tests. */
+int qh_mer_hash(int k, const uint64_t* mers, size_t n, uint64_t* hashes);
+
 /* Number of leading bytes of a FASTQ buffer that form whole groups of 4 lines:
  * where the CLI cuts a stream into chunks for the GPU fast path. */
 size_t qh_fastq_4line_prefix(const char* buf, size_t len, int final_chunk);

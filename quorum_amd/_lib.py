@@ -68,6 +68,7 @@ SIGNATURES = [
     ("qh_build_add_mers_device", C.c_int, [_p, _p, C.c_size_t]),
     ("qh_build_add_hashed_device", C.c_int, [_p, _p, C.c_size_t]),
     ("qh_detect_min_qual_char", C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
+    ("qh_mer_hash", C.c_int, [C.c_int, _u64p, C.c_size_t, _u64p]),
     ("qh_host_alloc", C.c_int, [C.POINTER(_p), C.c_size_t]),
     ("qh_host_free", None, [_p]),
     ("qh_build_sync", C.c_int, [_p]),

@@ -67,9 +67,10 @@ bool qh_make_geom(int k, int bits, uint64_t size, int min_qual, int reprobe_limi
   g.max_reprobe = (int)((uint64_t)reprobe_limit < maxr ? (uint64_t)reprobe_limit : maxr);
   g.pbits = bitsize((uint64_t)g.max_reprobe + 1);
   const int gsize = lsize + shard_bits;
-  g.rbits = 2 * k > gsize ? 2 * k - gsize : 0;
+  g.rbits = 2 * k + 1 > gsize ? 2 * k + 1 - gsize : 0;  // the hash is one bit wider than the key (qh_spec.h)
   g.min_qual = min_qual;
   g.kmask = qh_low_mask(2 * k);
+  g.hmask = qh_low_mask(2 * k + 1);
   g.vmask = qh_low_mask(g.vbits);
   g.max_val = ~0ull >> (64 - bits);  // mer_database.hpp:83
   if (g.vbits + g.pbits + g.rbits > 64) {
@@ -973,6 +974,14 @@ extern "C" int qh_detect_min_qual_char(const char* buf, size_t len, int* min_q_c
   if (minq != 33 && minq != 59 && minq != 64)
     return qh_fail(QH_EFORMAT, "Found an unusual minimum quality char of %d (%c). Stopping now. Use option -m to override",
                    minq, minq >= 32 && minq < 127 ? minq : '?');
+  return QH_OK;
+}
+
+extern "C" int qh_mer_hash(int k, const uint64_t* mers, size_t n, uint64_t* hashes) {
+  if (k < 1 || k > 31) return qh_fail(QH_EBADARG, "Mer length must be between 1 and 31 (got %d)", k);
+  if (n && (!mers || !hashes)) return qh_fail(QH_EBADARG, "null buffer");
+  const uint64_t kmask = qh_low_mask(2 * k);
+  for (size_t i = 0; i < n; ++i) hashes[i] = qh_hash_key(mers[i] & kmask, k);
   return QH_OK;
 }
 

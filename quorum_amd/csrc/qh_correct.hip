@@ -92,7 +92,7 @@ __device__ __forceinline__ void ec_replace0(ec_mer& m, int k, uint32_t y) {  // 
 __device__ __forceinline__ uint64_t ec_hash(const ec_mer& m, int k) {
   uint32_t c0, c1;
   qh_canonical_planes(m.a0, m.a1, m.b0, m.b1, &c0, &c1);
-  return qh_mix2(c0, c1, k);
+  return qh_mix_pair(c0, c1, m.a0 ^ m.b0 ^ c0, m.a1 ^ m.b1 ^ c1, k);
 }
 __device__ __forceinline__ uint32_t ec_code0(const ec_mer& m) { return (m.a0 & 1u) | ((m.a1 & 1u) << 1); }
 
@@ -187,9 +187,54 @@ __device__ __forceinline__ typename ec_word<NARROW>::type ec_lookup(const qh_geo
   return v[0];
 }
 
-// database_query::get_best_alternatives (mer_database.hpp:302-329): the four first probes are
-// issued together, the fold runs in the order of the forward strand's codes like the upstream loop
-// (the candidate with a-strand code y is the forward code y when d > 0 and 3 - y when d < 0)
+// The four siblings of get_best_alternatives in ONE probe sequence. The position hash takes its low
+// bits from the canonical core (bases 1..k-2, qh_spec.h), which the four mers that differ in base 0
+// share in whichever orientation their canonical forms lie: they have the same home slot and, probing
+// being linear, sit in the same one or two 64-byte lines. One walk from the home slot compares every
+// slot with the four tags; it ends when all four are found, at the first empty slot (whatever is still
+// missing is absent) or at the reprobe limit -- exactly where the four separate walks would end.
+// Needs lsize + shard_bits <= 2(k-2) (the home must not depend on the end bases) and wbits >= 3.
+template <bool NARROW>
+__device__ __forceinline__ void ec_lookup_siblings(const qh_geom& g, const uint64_t* __restrict__ table,
+                                                   const uint64_t (&h)[4], typename ec_word<NARROW>::type (&w)[4]) {
+  typedef typename ec_word<NARROW>::type W;
+  const uint32_t wmask = (1u << g.wbits) - 1u;
+  const int gsize = g.lsize + g.shard_bits;
+  const qh_pos p = qh_locate_hash(g, h[0]);
+  W tag[4];
+#pragma unroll
+  for (int y = 0; y < 4; ++y) { w[y] = 0; tag[y] = (W)((h[y] >> gsize) << g.pbits); }
+  if (p.shard != (uint32_t)g.shard_id) return;
+  uint64_t gaddr = p.home & ~(uint64_t)(EC_GROUP - 1);
+  int pi = -(int)((uint32_t)p.home & (uint32_t)(EC_GROUP - 1));
+  uint32_t pend = 15u;
+  for (;;) {
+    const ec_group grp = *reinterpret_cast<const ec_group*>(table + gaddr);
+#pragma unroll
+    for (int j = 0; j < EC_GROUP; ++j) {
+      const int idx = pi + j;
+      const uint64_t sj = grp.s[j];
+      if (pend && idx >= 0) {
+        if (idx > g.max_reprobe || sj == 0) pend = 0;
+        else {
+          // (remainder | probe + 1) - (idx + 1) has zero probe bits iff the slot was filled at this probe index
+          const W t = (W)(sj >> g.vbits) - (W)(idx + 1);
+#pragma unroll
+          for (int y = 0; y < 4; ++y)
+            if (t == tag[y]) { w[y] = (W)sj & (W)g.vmask; pend &= ~(1u << y); }
+        }
+      }
+    }
+    if (!pend) break;
+    gaddr = (gaddr & ~(uint64_t)wmask) | (((uint32_t)gaddr + (uint32_t)EC_GROUP) & wmask);
+    pi += EC_GROUP;
+  }
+}
+
+// database_query::get_best_alternatives (mer_database.hpp:302-329): one walk for the four siblings
+// (or four lookups advancing together where the table is too small for that); the fold runs in the
+// order of the forward strand's codes like the upstream loop (the candidate with a-strand code y is
+// the forward code y when d > 0 and 3 - y when d < 0)
 template <bool NARROW>
 __device__ __forceinline__ int ec_best_alternatives(const qh_geom& g, const uint64_t* __restrict__ table,
                                                     const ec_mer& m, int d, typename ec_word<NARROW>::type (&counts)[4],
@@ -207,6 +252,8 @@ __device__ __forceinline__ int ec_best_alternatives(const qh_geom& g, const uint
   if (g.wbits < 3) {
 #pragma unroll
     for (int y = 0; y < 4; ++y) w[y] = (W)ec_lookup_narrow_table(g, table, h[y]);
+  } else if (k >= 4 && g.lsize + g.shard_bits <= 2 * (k - 2)) {
+    ec_lookup_siblings<NARROW>(g, table, h, w);
   } else {
     ec_lookup_wide<4, NARROW>(g, table, h, w);
   }

@@ -285,7 +285,7 @@ void qh_header_from_geom(const qh_geom& g, qh_file_header& h) {
   h.key_bytes = h.size * 8;
   h.value_bytes = qh_vals_bytes(h.size, g.vbits);
   h.layout = "slot64/1";
-  h.hash = "feistel3-planes/1";
+  h.hash = "feistel3-core/2";
   h.window_bits = g.wbits;
   h.probe_bits = g.pbits;
   h.shard_bits = g.shard_bits;
@@ -293,8 +293,8 @@ void qh_header_from_geom(const qh_geom& g, qh_file_header& h) {
 
 bool qh_geom_from_header(const qh_file_header& h, qh_geom& g, std::string& err) {
   if (h.format != "binary/quorum_db") { err = "Wrong type '" + h.format + "'"; return false; }  // mer_database.hpp:264-265
-  if (h.layout != "slot64/1" || h.hash != "feistel3-planes/1") {
-    err = "keys image layout '" + h.layout + "'/hash '" + h.hash + "' is not the native slot64/1 + feistel3-planes/1 (upstream Jellyfish images are not readable)";
+  if (h.layout != "slot64/1" || h.hash != "feistel3-core/2") {
+    err = "keys image layout '" + h.layout + "'/hash '" + h.hash + "' is not the native slot64/1 + feistel3-core/2 (upstream Jellyfish images are not readable)";
     return false;
   }
   if (h.size == 0 || (h.size & (h.size - 1))) { err = "size is not a power of two"; return false; }

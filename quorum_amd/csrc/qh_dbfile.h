@@ -36,7 +36,7 @@ struct qh_file_header {
   // native layout parameters ("qhip" object)
   std::string layout;        // "slot64/1"
   uint32_t window_bits = 0, probe_bits = 0, shard_bits = 0;
-  std::string hash;          // "feistel3-planes/1"
+  std::string hash;          // "feistel3-core/2"
   std::vector<std::string> cmdline;
   std::string hostname, pwd, time, exe_path;
 };

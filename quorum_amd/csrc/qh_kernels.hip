@@ -235,7 +235,7 @@ __global__ __launch_bounds__(QH_BLOCK) void k_insert_items(const uint64_t* __res
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t it = items[i];
     const uint32_t q = (uint32_t)(it & 1);
-    const uint64_t h = hashed ? ((it >> 1) & g.kmask) : qh_hash_key((it >> 1) & g.kmask, g.k);
+    const uint64_t h = hashed ? ((it >> 1) & g.hmask) : qh_hash_key((it >> 1) & g.kmask, g.k);
     const qh_pos p = qh_locate_hash(g, h);
     if (p.shard != (uint32_t)g.shard_id) { ++n_foreign; continue; }
     ++n_inst; n_hq += q;

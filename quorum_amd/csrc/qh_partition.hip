@@ -277,7 +277,8 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
             const uint32_t m0 = (uint32_t)(f0 >> (QP_SEG - 1 - j)) & kones, m1 = (uint32_t)(f1 >> (QP_SEG - 1 - j)) & kones;
             uint32_t c0, c1;
             qh_canonical_planes(m0, m1, r0, r1, &c0, &c1);
-            const uint64_t h = qh_mix2(c0, c1, g.k);
+            // both orientations are at hand: the hash takes the smaller core of the two (qh_spec.h)
+            const uint64_t h = qh_mix_pair(c0, c1, m0 ^ r0 ^ c0, m1 ^ r1 ^ c1, g.k);
             if (p.check_owner && ((uint32_t)h & smask) != (uint32_t)g.shard_id) {
               ++n_foreign;
             } else {
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
       for (int i = 0; i < QP_BLOCKS_PER_WAVE; ++i) {
         if (raw[i] != QP_NONE) {
           const uint32_t q = (uint32_t)(raw[i] & 1);
-          const uint64_t h = p.in_hashed ? ((raw[i] >> 1) & g.kmask) : qh_hash_key((raw[i] >> 1) & g.kmask, g.k);
+          const uint64_t h = p.in_hashed ? ((raw[i] >> 1) & g.hmask) : qh_hash_key((raw[i] >> 1) & g.kmask, g.k);
           if (p.check_owner && ((uint32_t)h & smask) != (uint32_t)g.shard_id) {
             ++n_foreign;
           } else {

@@ -15,11 +15,12 @@
 //                                          low bits of the k codes | high bits << k
 //                                          (a fixed bit permutation of the 2-bit packing;
 //                                          it is what the wave-parallel extractor produces)
-// h   = qh_mix(pk)                         bijection on 2k-bit integers
+// h   = qh_mix(pk)                         injection of the 2k-bit keys into 2k+1-bit integers whose low
+//                                          bits depend only on the canonical CORE (bases 1..k-2)
 // owner shard = h & (2^shard_bits - 1)     (0 when the table is not sharded; it does
 //                                           not depend on lsize, so a shard can double)
 // local home  = (h >> shard_bits) & (2^lsize - 1)
-// remainder   = h >> gsize                 gsize = lsize + shard_bits, rbits = max(0, 2k - gsize)
+// remainder   = h >> gsize                 gsize = lsize + shard_bits, rbits = max(0, 2k + 1 - gsize)
 // probing     = linear inside the 2^wbits-slot window that contains the home
 //               slot: idx = (home & ~wmask) | ((home + i) & wmask), i <= max_reprobe
 // A slot is empty iff the whole word is 0 (an occupied slot has probe+1 >= 1).
@@ -41,6 +42,11 @@
 #define QH_MIX_C1 0x9E3779B1u
 #define QH_MIX_C2 0x85EBCA77u
 #define QH_MIX_C3 0xC2B2AE3Du
+// XORed into the core's hash: with it the all-ones 63-bit pattern is the hash of NO 31-mer (its preimage
+// is a core larger than its reverse complement, which is never the one hashed), so the all-ones item
+// (hash << 1 | 1 = ~0) stays free as the "no item" mark of the partition kernels at k = 31.
+// tests/test_dist_cpu.py checks this.
+#define QH_MIX_Z 5u
 
 struct qh_geom {
   int32_t k;            // mer length, 1..31
@@ -56,25 +62,79 @@ struct qh_geom {
   int32_t min_qual;     // threshold, compared as signed char
   int32_t all_shards;   // 1: this table is the concatenation of all 2^shard_bits shards
   uint64_t kmask;       // 2^(2k) - 1
+  uint64_t hmask;       // 2^(2k+1) - 1: the hash of a key is one bit wider than the key
   uint64_t vmask;       // 2^vbits - 1
   uint64_t max_val;     // 2^bits - 1
 };
 
 QH_HD uint64_t qh_low_mask(int n) { return n >= 64 ? ~0ULL : ((1ULL << n) - 1); }
 
-// Position hash: a 3-round Feistel network on the two k-bit halves of the plane key
-// (L = low code bits, R = high code bits), round function = top k bits of a 32-bit odd
-// multiply. Any Feistel network is a bijection of [0, 2^2k), so the stored remainder + home
-// position determine the key. The half updated twice (R) becomes the LOW half of the hash: it
-// carries the shard / window / slot bits. 32-bit arithmetic only: the wide multiplies of a
-// 64-bit mixer are quarter rate on CDNA and were ~45 % of the extraction kernel's VALU time.
-// (k <= 31 is enforced at qh_make_geom.)
-QH_HD uint64_t qh_mix2(uint32_t L, uint32_t R, int k) {
-  const int sh = 32 - k;
+// Position hash ("feistel3-core/2"). The key is the k-mer AS GIVEN (hash_with_quality::add does not
+// canonicalise, src/mer_database.hpp:94), seen as plane halves L = low code bits, R = high code bits.
+// Its CORE = bases 1 .. k-2, taken in whichever orientation (as is, or reverse complemented) is the
+// smaller 2(k-2)-bit number, goes through a 3-round Feistel network (round function = top k-2 bits of a
+// 32-bit odd multiply; 64-bit multiplies are quarter rate on CDNA) and supplies the LOW bits of the hash:
+// shard, window and home slot. The four end-base bits and the orientation bit sit above it:
+//
+//   h = [ flip : 1 ][ ends : 4 ][ Feistel(canonical core) : 2(k-2) ]            (2k + 1 bits)
+//
+// A Feistel network is a bijection, so h determines the key (qh_unmix) and the stored remainder + home
+// position reproduce it. Why the core: the corrector asks for the four k-mers that differ in their first
+// or last base (database_query::get_best_alternatives, src/mer_database.hpp:302-329) at every base of
+// every read; after canonicalisation those siblings are spread over both orientations, but all of them
+// share the canonical core, hence the home slot, hence (linear probing) one or two 64-byte lines of
+// HBM instead of four random ones. For k < 4 there is no core: the whole key goes through the network.
+QH_HD uint32_t qh_brev32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __brev(x);
+#else
+  x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+  x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+  x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+  x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+  return (x >> 16) | (x << 16);
+#endif
+}
+
+// planes of the reverse complement of an n-base sequence given as planes (base i at bit i), 1 <= n <= 31
+QH_HD void qh_rc_planes(uint32_t L, uint32_t R, int n, uint32_t* rL, uint32_t* rR) {
+  *rL = (~qh_brev32(L)) >> (32 - n);
+  *rR = (~qh_brev32(R)) >> (32 - n);
+}
+
+// (aL, aR) > (bL, bR) as 2-bit packed integers: decided at the most significant base that differs
+QH_HD bool qh_planes_greater(uint32_t aL, uint32_t aR, uint32_t bL, uint32_t bR) {
+  const uint32_t d1 = aR ^ bR, d = (aL ^ bL) | d1;
+  if (d == 0) return false;
+  const uint32_t bit = 0x80000000u >> __builtin_clz(d);
+  return ((d1 & bit) ? (aR & bit) : (aL & bit)) != 0;
+}
+
+QH_HD uint64_t qh_feistel3(uint32_t L, uint32_t R, int n) {
+  const int sh = 32 - n;
   R ^= (L * QH_MIX_C1) >> sh;
   L ^= (R * QH_MIX_C2) >> sh;
   R ^= (L * QH_MIX_C3) >> sh;
-  return (uint64_t)R | ((uint64_t)L << k);
+  return (uint64_t)R | ((uint64_t)L << n);
+}
+
+// hash of the key with planes (L, R) whose reverse complement has planes (oL, oR)
+QH_HD uint64_t qh_mix_pair(uint32_t L, uint32_t R, uint32_t oL, uint32_t oR, int k) {
+  if (k < 4) return qh_feistel3(L, R, k);
+  const int kc = k - 2;
+  const uint32_t cm = (1u << kc) - 1u;
+  uint32_t cL = (L >> 1) & cm, cR = (R >> 1) & cm;
+  const uint32_t dL = (oL >> 1) & cm, dR = (oR >> 1) & cm;
+  const bool flip = qh_planes_greater(cL, cR, dL, dR);
+  if (flip) { cL = dL; cR = dR; }
+  const uint32_t e = (L & 1u) | ((R & 1u) << 1) | ((L >> (k - 1)) << 2) | ((R >> (k - 1)) << 3);
+  return (qh_feistel3(cL, cR, kc) ^ QH_MIX_Z) | ((uint64_t)e << (2 * kc)) | ((uint64_t)flip << (2 * kc + 4));
+}
+
+QH_HD uint64_t qh_mix2(uint32_t L, uint32_t R, int k) {
+  uint32_t oL, oR;
+  qh_rc_planes(L, R, k, &oL, &oR);
+  return qh_mix_pair(L, R, oL, oR, k);
 }
 
 QH_HD uint64_t qh_mix(uint64_t x, int k) {
@@ -82,13 +142,27 @@ QH_HD uint64_t qh_mix(uint64_t x, int k) {
   return qh_mix2((uint32_t)x & km, (uint32_t)(x >> k) & km, k);
 }
 
-QH_HD uint64_t qh_unmix(uint64_t x, int k) {
-  const uint32_t km = (uint32_t)((1ull << k) - 1);
-  const int sh = 32 - k;
-  uint32_t R = (uint32_t)x & km, L = (uint32_t)(x >> k) & km;
+QH_HD uint64_t qh_unfeistel3(uint64_t x, int n) {
+  const uint32_t nm = (uint32_t)((1ull << n) - 1);
+  const int sh = 32 - n;
+  uint32_t R = (uint32_t)x & nm, L = (uint32_t)(x >> n) & nm;
   R ^= (L * QH_MIX_C3) >> sh;
   L ^= (R * QH_MIX_C2) >> sh;
   R ^= (L * QH_MIX_C1) >> sh;
+  return (uint64_t)L | ((uint64_t)R << n);
+}
+
+// hash -> plane key (low code bits | high code bits << k)
+QH_HD uint64_t qh_unmix(uint64_t h, int k) {
+  if (k < 4) return qh_unfeistel3(h, k);
+  const int kc = k - 2;
+  const uint32_t cm = (1u << kc) - 1u;
+  const uint64_t c = qh_unfeistel3((h & qh_low_mask(2 * kc)) ^ QH_MIX_Z, kc);
+  uint32_t cL = (uint32_t)c & cm, cR = (uint32_t)(c >> kc) & cm;
+  const uint32_t e = (uint32_t)(h >> (2 * kc)) & 15u;
+  if ((h >> (2 * kc + 4)) & 1u) qh_rc_planes(cL, cR, kc, &cL, &cR);
+  const uint32_t L = (cL << 1) | (e & 1u) | (((e >> 2) & 1u) << (k - 1));
+  const uint32_t R = (cR << 1) | ((e >> 1) & 1u) | (((e >> 3) & 1u) << (k - 1));
   return (uint64_t)L | ((uint64_t)R << k);
 }
 
@@ -191,7 +265,7 @@ QH_HD uint64_t qh_slot_hash(const qh_geom& g, uint64_t slot, uint64_t idx) {
   const uint64_t shard = g.all_shards ? home >> g.lsize : (uint64_t)g.shard_id;
   uint64_t h = ((home & qh_low_mask(g.lsize)) << g.shard_bits) | shard;
   if (gsize < 64) h |= rem << gsize;
-  return h & g.kmask;
+  return h & g.hmask;
 }
 
 // key stored in the occupied slot word `slot` found at index `idx`

@@ -46,26 +46,77 @@ def key_from_pkey_np(pk, k):
     return _spread_even(pk & km) | (_spread_even((pk >> np.uint64(k)) & km) << np.uint64(1))
 
 
+MIX_Z = np.uint64(5)
+_M32 = np.uint64(0xFFFFFFFF)
+
+
+def _feistel3(L, R, n):
+    nn, sh = np.uint64(n), np.uint64(32 - n)
+    R = R ^ (((L * MIX_C1) & _M32) >> sh)
+    L = L ^ (((R * MIX_C2) & _M32) >> sh)
+    R = R ^ (((L * MIX_C3) & _M32) >> sh)
+    return R | (L << nn)
+
+
+def _unfeistel3(x, n):
+    nm, nn, sh = np.uint64((1 << n) - 1), np.uint64(n), np.uint64(32 - n)
+    R, L = x & nm, (x >> nn) & nm
+    R = R ^ (((L * MIX_C3) & _M32) >> sh)
+    L = L ^ (((R * MIX_C2) & _M32) >> sh)
+    R = R ^ (((L * MIX_C1) & _M32) >> sh)
+    return L, R
+
+
+def _rc_planes(L, R, n):
+    """planes of the reverse complement of an n-base sequence (base i at bit i)"""
+    rL, rR = np.zeros_like(L), np.zeros_like(R)
+    one = np.uint64(1)
+    for i in range(n):
+        rL |= ((~(L >> np.uint64(i))) & one) << np.uint64(n - 1 - i)
+        rR |= ((~(R >> np.uint64(i))) & one) << np.uint64(n - 1 - i)
+    return rL, rR
+
+
+def _packed(L, R):
+    return _spread_even(L) | (_spread_even(R) << np.uint64(1))
+
+
 def mix_np(x, k):
-    """qh_mix (quorum_amd/csrc/qh_spec.h) on a uint64 array of plane keys: 3-round Feistel on the
-    two k-bit halves, the twice-updated half ending up low"""
+    """qh_mix (quorum_amd/csrc/qh_spec.h, "feistel3-core/2") on a uint64 array of plane keys:
+    h = [flip | 4 end-base bits | Feistel(canonical core) ^ Z]; the low bits (shard, window, home slot)
+    depend only on the canonical core = bases 1..k-2 in their smaller orientation"""
     x = np.asarray(x, dtype=np.uint64)
-    km, kk, sh, m32 = np.uint64((1 << k) - 1), np.uint64(k), np.uint64(32 - k), np.uint64(0xFFFFFFFF)
+    km, kk = np.uint64((1 << k) - 1), np.uint64(k)
     L, R = x & km, (x >> kk) & km
-    R = R ^ (((L * MIX_C1) & m32) >> sh)
-    L = L ^ (((R * MIX_C2) & m32) >> sh)
-    R = R ^ (((L * MIX_C3) & m32) >> sh)
-    return R | (L << kk)
+    if k < 4:
+        return _feistel3(L, R, k)
+    kc = k - 2
+    cm, one = np.uint64((1 << kc) - 1), np.uint64(1)
+    cL, cR = (L >> one) & cm, (R >> one) & cm
+    dL, dR = _rc_planes(cL, cR, kc)
+    flip = _packed(cL, cR) > _packed(dL, dR)
+    cL, cR = np.where(flip, dL, cL), np.where(flip, dR, cR)
+    top = np.uint64(k - 1)
+    e = (L & one) | ((R & one) << one) | ((L >> top) << np.uint64(2)) | ((R >> top) << np.uint64(3))
+    return (_feistel3(cL, cR, kc) ^ MIX_Z) | (e << np.uint64(2 * kc)) | (flip.astype(np.uint64) << np.uint64(2 * kc + 4))
 
 
-def unmix_np(x, k):
-    x = np.asarray(x, dtype=np.uint64)
-    km, kk, sh, m32 = np.uint64((1 << k) - 1), np.uint64(k), np.uint64(32 - k), np.uint64(0xFFFFFFFF)
-    R, L = x & km, (x >> kk) & km
-    R = R ^ (((L * MIX_C3) & m32) >> sh)
-    L = L ^ (((R * MIX_C2) & m32) >> sh)
-    R = R ^ (((L * MIX_C1) & m32) >> sh)
-    return L | (R << kk)
+def unmix_np(h, k):
+    h = np.asarray(h, dtype=np.uint64)
+    if k < 4:
+        L, R = _unfeistel3(h, k)
+        return L | (R << np.uint64(k))
+    kc = k - 2
+    one = np.uint64(1)
+    cL, cR = _unfeistel3((h & np.uint64((1 << (2 * kc)) - 1)) ^ MIX_Z, kc)
+    e = (h >> np.uint64(2 * kc)) & np.uint64(15)
+    flip = ((h >> np.uint64(2 * kc + 4)) & one) != 0
+    dL, dR = _rc_planes(cL, cR, kc)
+    cL, cR = np.where(flip, dL, cL), np.where(flip, dR, cR)
+    top = np.uint64(k - 1)
+    L = (cL << one) | (e & one) | (((e >> np.uint64(2)) & one) << top)
+    R = (cR << one) | ((e >> one) & one) | (((e >> np.uint64(3)) & one) << top)
+    return L | (R << np.uint64(k))
 
 
 def hash_np(mers, k):

@@ -93,17 +93,52 @@ def test_sharded_exchange_gloo(world, tmp_path):
 
 
 def test_mix_np_is_the_library_hash():
-    """dist_build.mix_np restates qh_mix; check bijectivity and the pinned constants"""
+    """dist_build.mix_np restates qh_mix ("feistel3-core/2"): equal to the library's host hash, injective,
+    invertible; the four end-base siblings of a mer share the low 2k-4 bits in both orientations; the
+    all-ones item is free at k = 31"""
+    import ctypes as C
     sys.path.insert(0, ROOT)
     from quorum_amd.dist_build import mix_np, unmix_np, pkey_np, key_from_pkey_np, hash_np, unhash_np
-    for k in (4, 5, 8):
+    from quorum_amd._lib import lib, check
+
+    def lib_hash(x, k):
+        x = np.ascontiguousarray(x, dtype=np.uint64)
+        out = np.empty_like(x)
+        u64p = C.POINTER(C.c_uint64)
+        check(lib.qh_mer_hash(k, x.ctypes.data_as(u64p), x.size, out.ctypes.data_as(u64p)))
+        return out
+
+    for k in (1, 3, 4, 5, 8):
         x = np.arange(4 ** k, dtype=np.uint64)
-        h = mix_np(x, k)
-        assert np.unique(h).size == x.size and int(h.max()) < 4 ** k
-        assert (unmix_np(h, k) == x).all()
         pk = pkey_np(x, k)
         assert np.unique(pk).size == x.size and (key_from_pkey_np(pk, k) == x).all()
-        assert (unhash_np(hash_np(x, k), k) == x).all()
+        h = hash_np(x, k)
+        assert (h == lib_hash(x, k)).all()
+        assert np.unique(h).size == x.size and int(h.max()) < 2 * 4 ** k
+        assert (unhash_np(h, k) == x).all()
+    rng = np.random.default_rng(5)
+    for k in (15, 24, 31):
+        x = rng.integers(0, 4 ** k, size=20000, dtype=np.uint64)
+        h = hash_np(x, k)
+        assert (h == lib_hash(x, k)).all() and (unhash_np(h, k) == x).all()
+        low = np.uint64((1 << (2 * k - 4)) - 1)
+        rc = np.array([_revcomp(int(m), k) for m in x[:2000]], dtype=np.uint64)
+        for b in range(4):
+            sib0 = (x[:2000] & ~np.uint64(3)) | np.uint64(b)                      # last base varied
+            sibk = (x[:2000] & ~(np.uint64(3) << np.uint64(2 * k - 2))) | (np.uint64(b) << np.uint64(2 * k - 2))
+            assert ((hash_np(sib0, k) & low) == (h[:2000] & low)).all()
+            assert ((hash_np(sibk, k) & low) == (h[:2000] & low)).all()
+        assert ((hash_np(rc, k) & low) == (h[:2000] & low)).all()                 # and the reverse complement
+    # the partition kernels mark "no item" with ~0 = (all-ones hash << 1 | 1): no 31-mer hashes to it
+    ones = np.array([(1 << 63) - 1], dtype=np.uint64)
+    assert hash_np(unhash_np(ones, 31), 31)[0] != ones[0]
     # ACGT = 00 01 10 11: low bits 0101 -> 0b0101, high bits 0011
     assert int(pkey_np(np.array([0x1B], dtype=np.uint64), 4)[0]) == 0b0011_0101
-    assert mix_np(np.array([0x123456789ABC], dtype=np.uint64), 24)[0] == mix_np(np.array([0x123456789ABC], dtype=np.uint64), 24)[0]
+
+
+def _revcomp(m, k):
+    r = 0
+    for _ in range(k):
+        r = (r << 2) | (3 - (m & 3))
+        m >>= 2
+    return r

@@ -78,7 +78,7 @@ def test_header_info_parses_reference_style_header(tmp_path):
     p = str(tmp_path / "db")
     hdr = {"format": "binary/quorum_db", "size": 1024, "key_len": 48, "val_len": 0, "max_reprobe": 126,
            "bits": 7, "key_bytes": 8192, "value_bytes": 1024, "cmdline": ["x", "-s", "1k"],
-           "qhip": {"layout": "slot64/1", "hash": "feistel3-planes/1", "window_bits": 10, "probe_bits": 7, "shard_bits": 0}}
+           "qhip": {"layout": "slot64/1", "hash": "feistel3-core/2", "window_bits": 10, "probe_bits": 7, "shard_bits": 0}}
     off = write_db_file(p, hdr, b"\0" * (8192 + 1024))
     info = _lib.QhDbInfo()
     assert _lib.lib.qh_db_header_info(p.encode(), C.byref(info)) == _lib.QH_OK
