@@ -195,15 +195,36 @@ __device__ __forceinline__ typename ec_word<NARROW>::type ec_lookup(const qh_geo
 // missing is absent) or at the reprobe limit -- exactly where the four separate walks would end.
 // Needs lsize + shard_bits <= 2(k-2) (the home must not depend on the end bases) and wbits >= 3.
 template <bool NARROW>
-__device__ __forceinline__ void ec_lookup_siblings(const qh_geom& g, const uint64_t* __restrict__ table,
-                                                   const uint64_t (&h)[4], typename ec_word<NARROW>::type (&w)[4]) {
+__device__ __forceinline__ void ec_lookup_siblings(const qh_geom& g, const uint64_t* __restrict__ table, const ec_mer& m,
+                                                   typename ec_word<NARROW>::type (&w)[4]) {
   typedef typename ec_word<NARROW>::type W;
+  const int k = g.k, kc = k - 2;
+  const uint32_t cm = (1u << kc) - 1u;
+  // the core both strands share, in its smaller orientation, and its hash: the siblings' common low bits
+  const uint32_t aL = (m.a0 >> 1) & cm, aR = (m.a1 >> 1) & cm, bL = (m.b0 >> 1) & cm, bR = (m.b1 >> 1) & cm;
+  const bool flip_a = qh_planes_greater(aL, aR, bL, bR);
+  const bool cores_eq = aL == bL && aR == bR;
+  const uint64_t F = qh_feistel3(flip_a ? bL : aL, flip_a ? bR : aR, kc) ^ QH_MIX_Z;
   const uint32_t wmask = (1u << g.wbits) - 1u;
   const int gsize = g.lsize + g.shard_bits;
-  const qh_pos p = qh_locate_hash(g, h[0]);
+  const qh_pos p = qh_locate_hash(g, F);
+  // sibling y = strand a with base 0 replaced by y, i.e. strand b with base k-1 replaced by 3 - y. Its key is
+  // the smaller of the two (kmer.hpp:43), decided at the top base, then by the cores, then at base 0; the
+  // key's end bases and the orientation of its core are the hash bits above the core's (qh_mix_pair)
+  const uint32_t a_top = ((m.a0 >> (k - 1)) & 1u) | (((m.a1 >> (k - 1)) & 1u) << 1);
+  const uint32_t b_low = (m.b0 & 1u) | ((m.b1 & 1u) << 1);
+  const W fhi = (W)(F >> gsize);
+  const int esh = 2 * kc - gsize;
   W tag[4];
 #pragma unroll
-  for (int y = 0; y < 4; ++y) { w[y] = 0; tag[y] = (W)((h[y] >> gsize) << g.pbits); }
+  for (uint32_t y = 0; y < 4; ++y) {
+    const uint32_t b_top = 3u - y;
+    const bool fwd = a_top != b_top ? a_top < b_top : (!cores_eq ? !flip_a : y <= b_low);
+    const uint32_t e = fwd ? (y | (a_top << 2)) : (b_low | (b_top << 2));
+    const uint32_t fl = fwd ? (uint32_t)flip_a : (uint32_t)(!cores_eq && !flip_a);
+    tag[y] = (fhi | ((W)(e | (fl << 4)) << esh)) << g.pbits;
+    w[y] = 0;
+  }
   if (p.shard != (uint32_t)g.shard_id) return;
   uint64_t gaddr = p.home & ~(uint64_t)(EC_GROUP - 1);
   int pi = -(int)((uint32_t)p.home & (uint32_t)(EC_GROUP - 1));
@@ -231,31 +252,33 @@ __device__ __forceinline__ void ec_lookup_siblings(const qh_geom& g, const uint6
   }
 }
 
-// database_query::get_best_alternatives (mer_database.hpp:302-329): one walk for the four siblings
-// (or four lookups advancing together where the table is too small for that); the fold runs in the
-// order of the forward strand's codes like the upstream loop (the candidate with a-strand code y is
-// the forward code y when d > 0 and 3 - y when d < 0)
-template <bool NARROW>
+// database_query::get_best_alternatives (mer_database.hpp:302-329): one walk for the four siblings (SIB;
+// otherwise four lookups advancing together); the fold runs in the order of the forward strand's codes
+// like the upstream loop (the candidate with a-strand code y is the forward code y when d > 0 and
+// 3 - y when d < 0)
+template <bool NARROW, bool SIB>
 __device__ __forceinline__ int ec_best_alternatives(const qh_geom& g, const uint64_t* __restrict__ table,
                                                     const ec_mer& m, int d, typename ec_word<NARROW>::type (&counts)[4],
                                                     int* ucode, int* level) {
   typedef typename ec_word<NARROW>::type W;
   const int k = g.k;
-  uint64_t h[4];
   W w[4];
-#pragma unroll
-  for (int y = 0; y < 4; ++y) {
-    ec_mer a = m;
-    ec_replace0(a, k, (uint32_t)y);
-    h[y] = ec_hash(a, k);
-  }
-  if (g.wbits < 3) {
-#pragma unroll
-    for (int y = 0; y < 4; ++y) w[y] = (W)ec_lookup_narrow_table(g, table, h[y]);
-  } else if (k >= 4 && g.lsize + g.shard_bits <= 2 * (k - 2)) {
-    ec_lookup_siblings<NARROW>(g, table, h, w);
+  if (SIB) {
+    ec_lookup_siblings<NARROW>(g, table, m, w);
   } else {
-    ec_lookup_wide<4, NARROW>(g, table, h, w);
+    uint64_t h[4];
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      ec_mer a = m;
+      ec_replace0(a, k, (uint32_t)y);
+      h[y] = ec_hash(a, k);
+    }
+    if (g.wbits < 3) {
+#pragma unroll
+      for (int y = 0; y < 4; ++y) w[y] = (W)ec_lookup_narrow_table(g, table, h[y]);
+    } else {
+      ec_lookup_wide<4, NARROW>(g, table, h, w);
+    }
   }
   int count = 0, lvl = 0;
 #pragma unroll
@@ -414,7 +437,7 @@ __device__ __forceinline__ double ec_poisson_term(double lambda, unsigned i) {  
   return exp(-lambda + i) * pow(lambda / i, (double)i) / sqrt(tau * i);
 }
 
-template <bool NARROW>
+template <bool NARROW, bool SIB>
 __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __restrict__ buf,
                                                             const uint4* __restrict__ recs,
                                                             const uint2* __restrict__ hdr,
@@ -524,7 +547,7 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
           if (!fin) {
             W counts[4];
             int ucode = 0, level;
-            const int count = ec_best_alternatives<NARROW>(P.g, table, mer, d, counts, &ucode, &level);
+            const int count = ec_best_alternatives<NARROW, SIB>(P.g, table, mer, d, counts, &ucode, &level);
             if (count == 1 && ucode == ori_code) {  // the read's base is the one continuation: the common case
               prev_count = (uint32_t)ec_sel4(counts, ucode);
               emit = true;
@@ -579,7 +602,7 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
                   ec_shift(nmer, k, km, d > 0 ? 0u : 3u);
                   W ncounts[4];
                   int nucode = 0, nlevel;
-                  const int ncount = ec_best_alternatives<NARROW>(P.g, table, nmer, d, ncounts, &nucode, &nlevel);
+                  const int ncount = ec_best_alternatives<NARROW, SIB>(P.g, table, nmer, d, ncounts, &nucode, &nlevel);
                   if (ncount > 0 && nlevel >= level) {
                     if (read_nbase_code >= 0 && ec_sel4(ncounts, read_nbase_code) > 0) cwcb |= 1u << i;
                     success = true;
@@ -864,6 +887,7 @@ struct qh_corrector {
   qh_ec_dev P;
   qh_ec_dev* d_P = nullptr;    // the same block in device memory (the kernel reads it through the scalar cache)
   bool narrow = false;         // value and tag fields fit 32 bits: the 32-bit kernel
+  bool siblings = false;       // the home slot does not depend on the end bases: one walk per get_best_alternatives
   uint32_t* d_ptab = nullptr;
   // chunk state
   uint8_t* d_chunk = nullptr;  size_t chunk_cap = 0;   // staging of host-fed chunks
@@ -945,6 +969,7 @@ static int corrector_init(qh_corrector* c) {
   const qh_geom& g = c->P.g;
   const qh_geom& cg = c->P.cg;
   c->narrow = g.vbits <= 32 && g.rbits + g.pbits <= 32 && (!c->P.ctable || (cg.vbits <= 32 && cg.rbits + cg.pbits <= 32));
+  c->siblings = g.k >= 4 && g.wbits >= 3 && g.lsize + g.shard_bits <= 2 * (g.k - 2);
   QH_HIP(hipMalloc((void**)&c->d_P, sizeof(qh_ec_dev)));
   QH_HIP(hipMemcpy(c->d_P, &c->P, sizeof(qh_ec_dev), hipMemcpyHostToDevice));
   return QH_OK;
@@ -1009,12 +1034,14 @@ static int enqueue_correct(qh_corrector* c, const uint8_t* dev_buf, size_t len, 
   unsigned grid = (rec_cap + EC_BLOCK - 1) / EC_BLOCK;
   if (grid > 256u * 16u) grid = 256u * 16u;
   if (grid < 1) grid = 1;
-  if (c->narrow)
-    hipLaunchKernelGGL(k_correct_reads<true>, dim3(grid), dim3(EC_BLOCK), 0, c->stream, dev_buf, c->d_recs, d_hdr, c->d_meta,
-                       c->d_P, c->P.table, c->P.ctable, c->P.ptab, c->d_obuf, c->d_logs, c->d_res, c->d_tot);
-  else
-    hipLaunchKernelGGL(k_correct_reads<false>, dim3(grid), dim3(EC_BLOCK), 0, c->stream, dev_buf, c->d_recs, d_hdr, c->d_meta,
-                       c->d_P, c->P.table, c->P.ctable, c->P.ptab, c->d_obuf, c->d_logs, c->d_res, c->d_tot);
+  auto launch = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(EC_BLOCK), 0, c->stream, dev_buf, c->d_recs, d_hdr, c->d_meta, c->d_P,
+                       c->P.table, c->P.ctable, c->P.ptab, c->d_obuf, c->d_logs, c->d_res, c->d_tot);
+  };
+  if (c->narrow && c->siblings) launch(k_correct_reads<true, true>);
+  else if (c->narrow) launch(k_correct_reads<true, false>);
+  else if (c->siblings) launch(k_correct_reads<false, true>);
+  else launch(k_correct_reads<false, false>);
   QH_HIP(hipEventRecord(c->ev[2], c->stream));
   hipLaunchKernelGGL(k_ec_block_sums, dim3(nblocks ? nblocks : 1), dim3(EC_FMT_BLOCK), 0, c->stream, c->d_res, c->d_meta,
                      c->d_bsums);
