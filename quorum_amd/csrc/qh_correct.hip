@@ -35,7 +35,7 @@
 #include "qh_device.h"
 
 #define EC_BLOCK 256
-#define EC_FMT_BLOCK 1024
+#define EC_FMT_BLOCK 256
 #define EC_RES_WORDS 8  // per read: status, start, end, nf, nb, offset of the backward log, fa_bytes, log_bytes
 
 enum { EC_ST_OK = 0, EC_ST_CONTAMINANT = 1, EC_ST_NO_START = 2, EC_ST_HOMOPOLYMER = 3 };
@@ -799,7 +799,12 @@ __global__ __launch_bounds__(1024) void k_ec_scan_blocks(unsigned long long* __r
   }
 }
 
-// every read writes its text: error_correct_reads.cc:272-275 (skipped) and :334-336 (corrected)
+// Every read writes its text: error_correct_reads.cc:272-275 (skipped) and :334-336 (corrected).
+// A block of 256 reads assembles its stretch of the .fa stream in LDS -- every lane the header and the
+// logs of its read, then each wave the corrected bases of its 64 reads one read at a time (coalesced
+// loads instead of 64 lanes reading 64 different lines) -- and streams it out in 16-byte units. A block
+// whose text does not fit (very long reads or logs) writes straight to global memory instead.
+#define EC_FMT_LDS 57344u
 __global__ __launch_bounds__(EC_FMT_BLOCK) void k_ec_format(const uint8_t* __restrict__ buf,
                                                             const uint4* __restrict__ recs,
                                                             const uint2* __restrict__ hdr,
@@ -811,67 +816,110 @@ __global__ __launch_bounds__(EC_FMT_BLOCK) void k_ec_format(const uint8_t* __res
                                                             const qh_ec_totals* __restrict__ tot,
                                                             uint8_t* __restrict__ fa, uint8_t* __restrict__ lgout) {
   __shared__ uint32_t sa[EC_FMT_BLOCK], sb[EC_FMT_BLOCK];
+  __shared__ uint32_t cp_src[EC_FMT_BLOCK], cp_dst[EC_FMT_BLOCK], cp_n[EC_FMT_BLOCK];
+  __shared__ __align__(16) uint8_t text[EC_FMT_LDS + 32];
   if (meta->format_err) return;
   const uint32_t nrec = meta->nrec;
-  const uint32_t r = blockIdx.x * EC_FMT_BLOCK + threadIdx.x;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t r = blockIdx.x * EC_FMT_BLOCK + tid;
+  if (blockIdx.x * EC_FMT_BLOCK >= nrec) return;
   uint4 r0 = make_uint4(0, 0, 0, 0), r1 = make_uint4(0, 0, 0, 0);
   if (r < nrec) {
     r0 = reinterpret_cast<const uint4*>(res + (size_t)r * EC_RES_WORDS)[0];
     r1 = reinterpret_cast<const uint4*>(res + (size_t)r * EC_RES_WORDS)[1];
   }
-  sa[threadIdx.x] = r1.z; sb[threadIdx.x] = r1.w;
+  sa[tid] = r1.z; sb[tid] = r1.w;
   __syncthreads();
   for (uint32_t o = 1; o < EC_FMT_BLOCK; o <<= 1) {
-    const uint32_t xa = threadIdx.x >= o ? sa[threadIdx.x - o] : 0, xb = threadIdx.x >= o ? sb[threadIdx.x - o] : 0;
+    const uint32_t xa = tid >= o ? sa[tid - o] : 0, xb = tid >= o ? sb[tid - o] : 0;
     __syncthreads();
-    sa[threadIdx.x] += xa; sb[threadIdx.x] += xb;
+    sa[tid] += xa; sb[tid] += xb;
     __syncthreads();
   }
-  if (r >= nrec) return;
-  const unsigned long long fa_off = bsums[2 * (size_t)blockIdx.x] + sa[threadIdx.x] - r1.z;
-  const unsigned long long lg_off = bsums[2 * (size_t)blockIdx.x + 1] + sb[threadIdx.x] - r1.w;
-  const uint4 rc = recs[r];
-  uint32_t hoff, hlen;
-  if (hdr) { hoff = hdr[r].x; hlen = hdr[r].y; }
-  else {
-    const uint32_t line = r ? recs[r - 1].z + recs[r - 1].y + 1u : 0u;
-    hoff = line + 1u;
-    hlen = rc.x - 1u - hoff;
-  }
-  const uint8_t* __restrict__ h = buf + hoff;
-  const uint32_t status = r0.x;
-  if (status == EC_ST_OK) {
-    if (tot->overflow & 1u) return;
-    uint8_t* w = fa + fa_off;
-    *w++ = '>';
-    for (uint32_t i = 0; i < hlen; ++i) *w++ = h[i];
-    *w++ = ' ';
-    w = ec_put_log(w, logs + (hdr ? rc.w : rc.x + 4u * r), r0.w, +1);
-    *w++ = ' ';
-    w = ec_put_log(w, logs + r1.y, r1.x, -1);
-    *w++ = '\n';
-    const uint8_t* __restrict__ o = obuf + rc.x;
-    for (int i = (int)r0.y; i < (int)r0.z; ++i) *w++ = o[i];
-    *w++ = '\n';
-  } else {
-    if (!(tot->overflow & 2u)) {
-      uint8_t* w = lgout + lg_off;
-      const char* const pre = "Skipped ";
-      for (int i = 0; i < 8; ++i) *w++ = (uint8_t)pre[i];
-      for (uint32_t i = 0; i < hlen; ++i) *w++ = h[i];
-      *w++ = ':'; *w++ = ' ';
-      const char* const msg = status == EC_ST_CONTAMINANT ? "Contaminated read"
-                              : status == EC_ST_NO_START  ? "No high quality mer"
-                                                          : "Entire read is an homopolymer";
-      const uint32_t ml = ec_error_text_bytes(status);
-      for (uint32_t i = 0; i < ml; ++i) *w++ = (uint8_t)msg[i];
-      *w++ = '\n';
+  const uint32_t block_bytes = sa[EC_FMT_BLOCK - 1];
+  const unsigned long long blk_off = bsums[2 * (size_t)blockIdx.x];
+  const bool fa_ok = !(tot->overflow & 1u);
+  const bool staged = block_bytes <= EC_FMT_LDS;
+  const uint32_t mis = (uint32_t)(blk_off & 15u);  // LDS copy congruent to the global offset modulo 16
+  const uint32_t loff = sa[tid] - r1.z;            // this read's offset inside the block's text
+  uint8_t* const wbase = staged ? text + mis : fa + blk_off;
+  cp_n[tid] = 0;
+  if (r < nrec) {
+    const unsigned long long lg_off = bsums[2 * (size_t)blockIdx.x + 1] + sb[tid] - r1.w;
+    const uint4 rc = recs[r];
+    uint32_t hoff, hlen;
+    if (hdr) { hoff = hdr[r].x; hlen = hdr[r].y; }
+    else {
+      const uint32_t line = r ? recs[r - 1].z + recs[r - 1].y + 1u : 0u;
+      hoff = line + 1u;
+      hlen = rc.x - 1u - hoff;
     }
-    if (r1.z && !(tot->overflow & 1u)) {  // -d: ">" header "\nN\n"
-      uint8_t* w = fa + fa_off;
-      *w++ = '>';
-      for (uint32_t i = 0; i < hlen; ++i) *w++ = h[i];
-      *w++ = '\n'; *w++ = 'N'; *w++ = '\n';
+    const uint8_t* __restrict__ h = buf + hoff;
+    const uint32_t status = r0.x;
+    if (status == EC_ST_OK) {
+      if (fa_ok) {
+        uint8_t* w = wbase + loff;
+        *w++ = '>';
+        for (uint32_t i = 0; i < hlen; ++i) *w++ = h[i];
+        *w++ = ' ';
+        w = ec_put_log(w, logs + (hdr ? rc.w : rc.x + 4u * r), r0.w, +1);
+        *w++ = ' ';
+        w = ec_put_log(w, logs + r1.y, r1.x, -1);
+        *w++ = '\n';
+        const uint32_t n = (int)r0.z > (int)r0.y ? r0.z - r0.y : 0u;
+        if (staged) {
+          cp_src[tid] = rc.x + r0.y;
+          cp_dst[tid] = (uint32_t)(w - wbase);
+          cp_n[tid] = n;
+        } else {
+          const uint8_t* __restrict__ o = obuf + rc.x + r0.y;
+          for (uint32_t i = 0; i < n; ++i) w[i] = o[i];
+        }
+        w[n] = '\n';
+      }
+    } else {
+      if (!(tot->overflow & 2u)) {
+        uint8_t* w = lgout + lg_off;
+        const char* const pre = "Skipped ";
+        for (int i = 0; i < 8; ++i) *w++ = (uint8_t)pre[i];
+        for (uint32_t i = 0; i < hlen; ++i) *w++ = h[i];
+        *w++ = ':'; *w++ = ' ';
+        const char* const msg = status == EC_ST_CONTAMINANT ? "Contaminated read"
+                                : status == EC_ST_NO_START  ? "No high quality mer"
+                                                            : "Entire read is an homopolymer";
+        const uint32_t ml = ec_error_text_bytes(status);
+        for (uint32_t i = 0; i < ml; ++i) *w++ = (uint8_t)msg[i];
+        *w++ = '\n';
+      }
+      if (r1.z && fa_ok) {  // -d: ">" header "\nN\n"
+        uint8_t* w = wbase + loff;
+        *w++ = '>';
+        for (uint32_t i = 0; i < hlen; ++i) *w++ = h[i];
+        *w++ = '\n'; *w++ = 'N'; *w++ = '\n';
+      }
+    }
+  }
+  if (!staged || !fa_ok) return;  // uniform over the block
+  __syncthreads();
+  // corrected bases: wave w copies the sequences of reads 64 w .. 64 w + 63, 64 bytes per step
+  const uint32_t lane = tid & 63u, w0 = tid & ~63u;
+  for (uint32_t i = 0; i < 64; ++i) {
+    const uint32_t n = cp_n[w0 + i];
+    if (!n) continue;
+    const uint8_t* __restrict__ src = obuf + cp_src[w0 + i];
+    uint8_t* dst = text + mis + cp_dst[w0 + i];
+    for (uint32_t b = lane; b < n; b += 64) dst[b] = src[b];
+  }
+  __syncthreads();
+  // stream the block's text out: whole 16-byte units as one store, the ragged ends byte by byte
+  const uint32_t end = mis + block_bytes, units = (end + 15u) / 16u;
+  uint8_t* const gbase = fa + (blk_off - mis);  // 16-byte aligned: fa comes from hipMalloc
+  for (uint32_t u = tid; u < units; u += EC_FMT_BLOCK) {
+    const uint32_t b0 = u * 16u;
+    if (b0 >= mis && b0 + 16u <= end) {
+      *reinterpret_cast<uint4*>(gbase + b0) = *reinterpret_cast<const uint4*>(text + b0);
+    } else {
+      for (uint32_t b = b0 < mis ? mis : b0; b < b0 + 16u && b < end; ++b) gbase[b] = text[b];
     }
   }
 }

@@ -129,6 +129,16 @@ def test_other_geometries(k, bits):
     q.close(); h.close(); odb.close()
 
 
+def test_long_reads_text_written_unstaged():
+    """256 reads of 400 bp do not fit the format kernel's LDS staging: the direct-write path"""
+    g = synth.make_genome(30000, seed=31)
+    fq = synth.make_fastq(g, 3000, 400, err=0.01, seed=32, tails=True).tobytes()
+    odb, h, q = build_pair(fq, 24)
+    check_parity(odb, q, fq, via="device")
+    check_parity(odb, q, fq, no_discard=True, anchor_count=50)
+    q.close(); h.close(); odb.close()
+
+
 def test_ragged_reads_and_odd_characters():
     """N, IUPAC, lowercase, reads around and below k, negative quality bytes, long headers"""
     rng = np.random.default_rng(11)
