@@ -228,25 +228,28 @@ __device__ __forceinline__ void ec_lookup_siblings(const qh_geom& g, const uint6
   if (p.shard != (uint32_t)g.shard_id) return;
   uint64_t gaddr = p.home & ~(uint64_t)(EC_GROUP - 1);
   int pi = -(int)((uint32_t)p.home & (uint32_t)(EC_GROUP - 1));
-  uint32_t pend = 15u;
+  uint32_t found = 0;
+  // Branch-free per line. A key is stored at the first empty slot of its probe sequence and slots are never
+  // emptied, so a slot whose (remainder, probe) fields match a tag at this probe index IS that key, whatever
+  // lies before it: only the slots outside [home, home + max_reprobe] must be kept from matching (their
+  // difference is forced to 1, which no tag equals: tags have zero probe bits). The walk ends with the
+  // line that holds an empty slot or the reprobe limit, or once all four siblings are found.
   for (;;) {
     const ec_group grp = *reinterpret_cast<const ec_group*>(table + gaddr);
+    bool stop = pi + EC_GROUP > g.max_reprobe;
 #pragma unroll
     for (int j = 0; j < EC_GROUP; ++j) {
       const int idx = pi + j;
       const uint64_t sj = grp.s[j];
-      if (pend && idx >= 0) {
-        if (idx > g.max_reprobe || sj == 0) pend = 0;
-        else {
-          // (remainder | probe + 1) - (idx + 1) has zero probe bits iff the slot was filled at this probe index
-          const W t = (W)(sj >> g.vbits) - (W)(idx + 1);
+      const bool valid = idx >= 0 && idx <= g.max_reprobe;
+      stop |= valid && sj == 0;
+      const W t = valid ? (W)(sj >> g.vbits) - (W)(idx + 1) : (W)1;
+      const W val = (W)sj & (W)g.vmask;
 #pragma unroll
-          for (int y = 0; y < 4; ++y)
-            if (t == tag[y]) { w[y] = (W)sj & (W)g.vmask; pend &= ~(1u << y); }
-        }
-      }
+      for (int y = 0; y < 4; ++y)
+        if (t == tag[y]) { w[y] = val; found |= 1u << y; }
     }
-    if (!pend) break;
+    if (stop || found == 15u) break;
     gaddr = (gaddr & ~(uint64_t)wmask) | (((uint32_t)gaddr + (uint32_t)EC_GROUP) & wmask);
     pi += EC_GROUP;
   }
