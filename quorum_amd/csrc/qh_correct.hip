@@ -774,9 +774,13 @@ __global__ __launch_bounds__(EC_FMT_BLOCK) void k_ec_block_sums(const uint32_t* 
 }
 
 // exclusive scan of the block sums (one workgroup), totals
-__global__ __launch_bounds__(1024) void k_ec_scan_blocks(unsigned long long* __restrict__ bsums, uint32_t nblocks,
+__global__ __launch_bounds__(1024) void k_ec_scan_blocks(unsigned long long* __restrict__ bsums, uint32_t nblocks_cap,
+                                                         const qh_meta* __restrict__ meta,
                                                          qh_ec_totals* __restrict__ tot) {
   __shared__ unsigned long long pa[1024], pb[1024];
+  // only the blocks that hold records (the capacity is sized from the chunk length, ~13 times more)
+  uint32_t nblocks = meta->format_err ? 0u : (meta->nrec + EC_FMT_BLOCK - 1) / EC_FMT_BLOCK;
+  if (nblocks > nblocks_cap) nblocks = nblocks_cap;
   const uint32_t per = (nblocks + 1023) / 1024;
   const uint32_t b0 = threadIdx.x * per;
   unsigned long long sa = 0, sb = 0;
@@ -1096,7 +1100,7 @@ static int enqueue_correct(qh_corrector* c, const uint8_t* dev_buf, size_t len, 
   QH_HIP(hipEventRecord(c->ev[2], c->stream));
   hipLaunchKernelGGL(k_ec_block_sums, dim3(nblocks ? nblocks : 1), dim3(EC_FMT_BLOCK), 0, c->stream, c->d_res, c->d_meta,
                      c->d_bsums);
-  hipLaunchKernelGGL(k_ec_scan_blocks, dim3(1), dim3(1024), 0, c->stream, c->d_bsums, nblocks ? nblocks : 1, c->d_tot);
+  hipLaunchKernelGGL(k_ec_scan_blocks, dim3(1), dim3(1024), 0, c->stream, c->d_bsums, nblocks ? nblocks : 1, c->d_meta, c->d_tot);
   launch_format(c);
   QH_HIP(hipEventRecord(c->ev[3], c->stream));
   QH_HIP(hipGetLastError());
