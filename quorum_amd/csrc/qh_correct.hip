@@ -440,8 +440,48 @@ __device__ __forceinline__ double ec_poisson_term(double lambda, unsigned i) {  
   return exp(-lambda + i) * pow(lambda / i, (double)i) / sqrt(tau * i);
 }
 
+// The read's characters and the corrected bases go through 16-byte register buffers: a lane touches
+// one base per step and 100-300 steps pass between the first and the last byte of a 64-byte line, far
+// longer than a line survives in L2 under the table traffic. Byte-wise, every step re-fetched the sequence
+// line (1.1 of the 2.4 HBM lines per base) and the byte stores reached HBM as partial-line writes
+// (5.7 GB written for 200 MB of bases).
+struct ec_rbuf {  // one aligned 16-byte block of the chunk
+  uint4 w;
+  uint32_t blk;
+};
+__device__ __forceinline__ uint8_t ec_read(ec_rbuf& r, const uint8_t* __restrict__ buf, size_t buf_len, uint32_t off) {
+  const uint32_t blk = off & ~15u;
+  if (blk != r.blk) { r.w = load16_guarded(buf, blk, buf_len); r.blk = blk; }
+  const uint32_t wi = (off >> 2) & 3u;
+  const uint32_t x = wi == 0 ? r.w.x : wi == 1 ? r.w.y : wi == 2 ? r.w.z : r.w.w;
+  return (uint8_t)(x >> (8u * (off & 3u)));
+}
+struct ec_wbuf {  // bytes written into one aligned 16-byte block of the output, not yet stored
+  uint32_t w[4];
+  uint32_t blk, mask;
+};
+__device__ __forceinline__ void ec_flush(ec_wbuf& b, uint8_t* __restrict__ obuf) {
+  if (b.mask == 0xFFFFu) {
+    *reinterpret_cast<uint4*>(obuf + b.blk) = make_uint4(b.w[0], b.w[1], b.w[2], b.w[3]);
+  } else if (b.mask) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if ((b.mask >> i) & 1u) obuf[b.blk + i] = (uint8_t)(b.w[i >> 2] >> (8 * (i & 3)));
+  }
+  b.mask = 0;
+}
+__device__ __forceinline__ void ec_write(ec_wbuf& b, uint8_t* __restrict__ obuf, uint32_t off, uint8_t c) {
+  const uint32_t blk = off & ~15u;
+  if (blk != b.blk) { ec_flush(b, obuf); b.blk = blk; }
+  const uint32_t wi = (off >> 2) & 3u, sh = 8u * (off & 3u);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (wi == (uint32_t)i) b.w[i] = (b.w[i] & ~(0xFFu << sh)) | ((uint32_t)c << sh);
+  b.mask |= 1u << (off & 15u);
+}
+
 template <bool NARROW, bool SIB>
-__global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __restrict__ buf,
+__global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __restrict__ buf, size_t buf_len,
                                                             const uint4* __restrict__ recs,
                                                             const uint2* __restrict__ hdr,
                                                             const qh_meta* __restrict__ meta,
@@ -464,8 +504,11 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
 
   for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nrec; r += gridDim.x * blockDim.x) {
     const uint4 rc = recs[r];
-    const uint8_t* __restrict__ seq = buf + rc.x;
     uint8_t* __restrict__ o = obuf + rc.x;
+    ec_rbuf rb;
+    rb.blk = 0xFFFFFFFFu;
+    ec_wbuf wb;
+    wb.blk = 0xFFFFFFFFu; wb.mask = 0;
     const int len = (int)rc.y;
     // strict 4-line chunks: consecutive sequences are >= 2 len + 6 bytes apart, so the word range
     // [seq_off + 4 r, + len + 4) is private to the read; host-parsed chunks carry the offset in .w
@@ -485,8 +528,8 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
     while (in < len && !anchored && status == EC_ST_OK) {
       int i = 0;
       while (in < len && i < k) {
-        const uint8_t c = seq[in];
-        o[in] = c;
+        const uint8_t c = ec_read(rb, buf, buf_len, rc.x + (uint32_t)in);
+        ec_write(wb, obuf, rc.x + (uint32_t)in, c);
         ++in;
         const int x = qh_code(c);
         if (x >= 0) { ec_shift(mer, k, km, (uint32_t)x); ++i; }
@@ -503,8 +546,8 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
           found = (int)val >= P.anchor ? found + 1 : 0;
           if (found >= P.good) { anchored = true; break; }
         }
-        const uint8_t c = seq[in];
-        o[in] = c;
+        const uint8_t c = ec_read(rb, buf, buf_len, rc.x + (uint32_t)in);
+        ec_write(wb, obuf, rc.x + (uint32_t)in, c);
         ++in;
         const int x = qh_code(c);
         if (x < 0) break;
@@ -529,12 +572,12 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
       int ip = start_off, pos = start_off, end = len, out = start_off;
       uint32_t prev_count = prev0;
       // the character under the head is loaded one step ahead: it never waits behind the lookups
-      uint8_t nbase = ip != end ? seq[ip] : (uint8_t)0;
+      uint8_t nbase = ip != end ? ec_read(rb, buf, buf_len, rc.x + (uint32_t)ip) : (uint8_t)0;
       for (;;) {
         bool fin = ip == end;
         if (!fin) {
           const uint8_t base = nbase;
-          nbase = ip + d != end ? seq[ip + d] : (uint8_t)0;
+          nbase = ip + d != end ? ec_read(rb, buf, buf_len, rc.x + (uint32_t)(ip + d)) : (uint8_t)0;
           if (base == '\n') { ip += d; continue; }
           const int cpos = pos;
           pos += d;
@@ -659,7 +702,7 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
           }
           if (emit) {  // *out++ = mer.base(0)
             const uint32_t c0 = ec_code0(mer);
-            o[out] = (uint8_t)names[d > 0 ? c0 : 3u - c0];
+            ec_write(wb, obuf, rc.x + (uint32_t)out, (uint8_t)names[d > 0 ? c0 : 3u - c0]);
             out += d;
           }
           ip += d;
@@ -675,7 +718,7 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
             mer.a0 = anchor_mer.b0; mer.a1 = anchor_mer.b1; mer.b0 = anchor_mer.a0; mer.b1 = anchor_mer.a1;
             ip = start_off - k - 1; pos = ip; end = -1; out = ip;
             prev_count = prev0;
-            nbase = ip != end ? seq[ip] : (uint8_t)0;
+            nbase = ip != end ? ec_read(rb, buf, buf_len, rc.x + (uint32_t)ip) : (uint8_t)0;
           } else {
             start_out = out + 1;
             nb = log.n;
@@ -685,6 +728,7 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
       }
     }
 
+    ec_flush(wb, obuf);
     uint32_t* __restrict__ lg = logs + log_off;
     // ---- homo_trim (error_correct_reads.cc:567-597)
     if (status == EC_ST_OK && P.do_homo_trim) {
@@ -1090,7 +1134,7 @@ static int enqueue_correct(qh_corrector* c, const uint8_t* dev_buf, size_t len, 
   if (grid > 256u * 16u) grid = 256u * 16u;
   if (grid < 1) grid = 1;
   auto launch = [&](auto kern) {
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(EC_BLOCK), 0, c->stream, dev_buf, c->d_recs, d_hdr, c->d_meta, c->d_P,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(EC_BLOCK), 0, c->stream, dev_buf, len, c->d_recs, d_hdr, c->d_meta, c->d_P,
                        c->P.table, c->P.ctable, c->P.ptab, c->d_obuf, c->d_logs, c->d_res, c->d_tot);
   };
   if (c->narrow && c->siblings) launch(k_correct_reads<true, true>);
