@@ -228,7 +228,6 @@ __device__ __forceinline__ void ec_lookup_siblings(const qh_geom& g, const uint6
   if (p.shard != (uint32_t)g.shard_id) return;
   uint64_t gaddr = p.home & ~(uint64_t)(EC_GROUP - 1);
   int pi = -(int)((uint32_t)p.home & (uint32_t)(EC_GROUP - 1));
-  uint32_t found = 0;
   // Branch-free per line. A key is stored at the first empty slot of its probe sequence and slots are never
   // emptied, so a slot whose (remainder, probe) fields match a tag at this probe index IS that key, whatever
   // lies before it: only the slots outside [home, home + max_reprobe] must be kept from matching (their
@@ -237,19 +236,19 @@ __device__ __forceinline__ void ec_lookup_siblings(const qh_geom& g, const uint6
   for (;;) {
     const ec_group grp = *reinterpret_cast<const ec_group*>(table + gaddr);
     bool stop = pi + EC_GROUP > g.max_reprobe;
+    const uint32_t span = (uint32_t)g.max_reprobe;  // valid slots: 0 <= pi + j <= max_reprobe
 #pragma unroll
     for (int j = 0; j < EC_GROUP; ++j) {
-      const int idx = pi + j;
       const uint64_t sj = grp.s[j];
-      const bool valid = idx >= 0 && idx <= g.max_reprobe;
+      const bool valid = (uint32_t)(pi + j) <= span;
       stop |= valid && sj == 0;
-      const W t = valid ? (W)(sj >> g.vbits) - (W)(idx + 1) : (W)1;
+      const W t = valid ? (W)(sj >> g.vbits) - (W)(pi + j + 1) : (W)1;
       const W val = (W)sj & (W)g.vmask;
 #pragma unroll
-      for (int y = 0; y < 4; ++y)
-        if (t == tag[y]) { w[y] = val; found |= 1u << y; }
+      for (int y = 0; y < 4; ++y) w[y] = t == tag[y] ? val : w[y];
     }
-    if (stop || found == 15u) break;
+    // a stored value is never 0 (count >= 1): all four found <=> all four non-zero
+    if (stop || (w[0] != 0 && w[1] != 0 && w[2] != 0 && w[3] != 0)) break;
     gaddr = (gaddr & ~(uint64_t)wmask) | (((uint32_t)gaddr + (uint32_t)EC_GROUP) & wmask);
     pi += EC_GROUP;
   }
@@ -498,7 +497,6 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
   const uint32_t nrec = meta->nrec;
   const int k = P.g.k;
   const uint32_t km = (uint32_t)((1ull << k) - 1);
-  const char* const names = "ACGT";
   uint32_t t_corrected = 0, t_skipped = 0, t_subs = 0, t_truncs = 0, t_reads = 0;
   unsigned long long t_in = 0, t_out = 0;
 
@@ -702,7 +700,7 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
           }
           if (emit) {  // *out++ = mer.base(0)
             const uint32_t c0 = ec_code0(mer);
-            ec_write(wb, obuf, rc.x + (uint32_t)out, (uint8_t)names[d > 0 ? c0 : 3u - c0]);
+            ec_write(wb, obuf, rc.x + (uint32_t)out, (uint8_t)(0x54474341u >> (8u * (d > 0 ? c0 : 3u - c0)))  /* "ACGT"[code] */);
             out += d;
           }
           ip += d;
