@@ -35,6 +35,9 @@
 #include "qh_device.h"
 
 #define EC_BLOCK 256
+#ifndef EC_WAVES
+#define EC_WAVES 4  // waves per SIMD the corrector kernel is compiled for: 128 VGPRs, a few spilled words (measured: 3 -> 4 waves 8.9 -> 7.5 ms)
+#endif
 #define EC_FMT_BLOCK 256
 #define EC_RES_WORDS 8  // per read: status, start, end, nf, nb, offset of the backward log, fa_bytes, log_bytes
 
@@ -480,7 +483,7 @@ __device__ __forceinline__ void ec_write(ec_wbuf& b, uint8_t* __restrict__ obuf,
 }
 
 template <bool NARROW, bool SIB>
-__global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __restrict__ buf, size_t buf_len,
+__global__ __launch_bounds__(EC_BLOCK) __attribute__((amdgpu_waves_per_eu(EC_WAVES, EC_WAVES))) void k_correct_reads(const uint8_t* __restrict__ buf, size_t buf_len,
                                                             const uint4* __restrict__ recs,
                                                             const uint2* __restrict__ hdr,
                                                             const qh_meta* __restrict__ meta,
@@ -636,10 +639,17 @@ __global__ __launch_bounds__(EC_BLOCK) void k_correct_reads(const uint8_t* __res
                 W cont_counts[4] = {0, 0, 0, 0};
                 uint32_t cwcb = 0;  // continue_with_correct_base, one bit per code
                 const int read_nbase_code = ip + d != end ? qh_code(nbase) : -1;
+                // upstream walks i = 0..3 and skips counts[i] <= min_count; here every lane walks ITS
+                // qualifying codes in ascending order, so the wave makes as many extra lookups as its
+                // busiest lane has candidates (usually one) instead of four
+                uint32_t qm = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) qm |= (uint32_t)((uint64_t)counts[i] > (uint64_t)P.min_count) << i;
 #pragma unroll 1
-                for (int i = 0; i < 4; ++i) {
+                while (qm) {
+                  const int i = __ffs((int)qm) - 1;
+                  qm &= qm - 1u;
                   const W ci = ec_sel4(counts, i);
-                  if ((uint64_t)ci <= (uint64_t)P.min_count) continue;
                   check_code = i;
                   ec_mer nmer = mer;
                   ec_replace0(nmer, k, (uint32_t)(d > 0 ? i : 3 - i));
