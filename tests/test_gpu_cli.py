@@ -140,3 +140,43 @@ def test_quorum_pipeline_cli_end_to_end(tmp_path):
     r = subprocess.run([os.path.join(BIN, "quorum_error_correct_reads"), str(tmp_path / "missing.jf"), "x"],
                        capture_output=True, text=True, timeout=60)
     assert r.returncode == 1
+
+
+def test_paired_end_pipeline(tmp_path):
+    """quorum's paired-end plumbing (src/quorum.in:172-231): merge_mate_pairs f1 f2 | error_correct_reads -d db
+    /dev/fd/0 2> log | split_mate_pairs prefix -- mates stay in step because -d keeps every read"""
+    k, bits = 24, 7
+    g = synth.make_genome(30000, seed=41)
+    fq1 = synth.make_fastq(g, 6000, 100, seed=42, tails=True).tobytes()
+    fq2 = synth.make_fastq(g, 6000, 100, seed=43, tails=True, first_id=6000).tobytes()
+    (tmp_path / "r1.fastq").write_bytes(fq1)
+    (tmp_path / "r2.fastq").write_bytes(fq2)
+    dbf = str(tmp_path / "db.jf")
+    r = subprocess.run([os.path.join(BIN, "quorum_create_database"), "-s", "1M", "-m", str(k), "-b", str(bits), "-q", "38",
+                        "-o", dbf, str(tmp_path / "r1.fastq"), str(tmp_path / "r2.fastq")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    merge = subprocess.Popen([os.path.join(BIN, "merge_mate_pairs"), str(tmp_path / "r1.fastq"), str(tmp_path / "r2.fastq")],
+                             stdout=subprocess.PIPE)
+    with open(tmp_path / "p.log", "wb") as lg:
+        correct = subprocess.Popen([os.path.join(BIN, "quorum_error_correct_reads"), "-d", "-a", "25", dbf, "/dev/fd/0"],
+                                   stdin=merge.stdout, stdout=subprocess.PIPE, stderr=lg,
+                                   env=dict(os.environ, QUORUM_HIP_CHUNK_MB="1"))
+        merge.stdout.close()
+        split = subprocess.Popen([os.path.join(BIN, "split_mate_pairs"), str(tmp_path / "p")], stdin=correct.stdout)
+        correct.stdout.close()
+        assert split.wait(timeout=300) == 0 and correct.wait(timeout=300) == 0 and merge.wait(timeout=300) == 0
+    db = po.OracleDB(1 << 20, k, bits)
+    db.add_fastq(fq1, 38)
+    db.add_fastq(fq2, 38)
+    cut = db.poisson_cutoff(0.01 / 3, 1e-6 / 0.01)
+    l1, l2 = fq1.split(b"\n"), fq2.split(b"\n")
+    inter = b"".join(b"\n".join(l1[i:i + 4]) + b"\n" + b"\n".join(l2[i:i + 4]) + b"\n" for i in range(0, len(l1) - 1, 4))
+    fa, lg, n = db.correct_fastq(inter, po.ec_params(cut, anchor=25, no_discard=True))
+    assert n == 12000 and lg.count(b"Skipped") > 10          # some reads are discarded: a single N keeps the pairing
+    out = fa.split(b"\n")
+    want1 = b"".join(out[i] + b"\n" + out[i + 1] + b"\n" for i in range(0, len(out) - 1, 4))
+    want2 = b"".join(out[i + 2] + b"\n" + out[i + 3] + b"\n" for i in range(0, len(out) - 1, 4))
+    assert (tmp_path / "p_1.fa").read_bytes() == want1
+    assert (tmp_path / "p_2.fa").read_bytes() == want2
+    assert (tmp_path / "p.log").read_bytes() == lg
+    assert (tmp_path / "p_1.fa").read_bytes().count(b">") == 6000

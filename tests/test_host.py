@@ -153,3 +153,33 @@ def test_detect_min_qual_char_like_the_driver():
     assert quorum_amd.detect_min_qual_char(fq(["hhhh"] * 999 + ["@hhh"] + ["!hhh"])) == 64
     with pytest.raises(quorum_amd.QhError, match="Invalid fastq format"):
         quorum_amd.detect_min_qual_char(b"@r0\nACGT\n+\n")
+
+
+def test_mate_pair_helpers(tmp_path):
+    """merge_mate_pairs (src/merge_mate_pairs.cc:50-91) interleaves the even and the odd files as 4-line
+    FASTQ ('*' qualities for FASTA records, multi-line records re-flowed); split_mate_pairs
+    (src/split_mate_pairs.cc:15-33) deals two-line records alternately to <prefix>_1.fa / _2.fa"""
+    import subprocess
+    bindir = os.path.join(ROOT, "quorum_amd", "bin")
+    a1 = b"@a1 x\nACGT\nAC\n+\nIIII\nII\n@a2\nGG\n+a2\nII\n"
+    b1 = b">b1\nTTTT\nTT\n>b2 y\nCC\n"
+    a2 = b"@a3\nA\n+\nI\n"
+    b2 = b"@b3\nC\n+\n#\n"
+    for n, d in (("a1", a1), ("b1", b1), ("a2", a2), ("b2", b2)):
+        (tmp_path / n).write_bytes(d)
+    r = subprocess.run([os.path.join(bindir, "merge_mate_pairs")] + [str(tmp_path / n) for n in ("a1", "b1", "a2", "b2")],
+                       capture_output=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == (b"@a1 x\nACGTAC\n+\nIIIIII\n@b1\nTTTTTT\n+\n******\n@a2\nGG\n+\nII\n@b2 y\nCC\n+\n**\n"
+                        b"@a3\nA\n+\nI\n@b3\nC\n+\n#\n")
+    r = subprocess.run([os.path.join(bindir, "merge_mate_pairs"), str(tmp_path / "a1"), str(tmp_path / "a2")],
+                       capture_output=True, timeout=60)
+    assert r.returncode != 0 and b"Input files are not paired reads." in r.stderr
+    r = subprocess.run([os.path.join(bindir, "merge_mate_pairs"), str(tmp_path / "a1"), str(tmp_path / "b1"), str(tmp_path / "a2")],
+                       capture_output=True, timeout=60)
+    assert r.returncode == 1 and b"Must give a even number files" in r.stderr
+    fa = b">a1 x 3:sub:A-C \nACCTAC\n>b1\nN\n>a2  \nGG\n>b2 y  \nCC\n"
+    r = subprocess.run([os.path.join(bindir, "split_mate_pairs"), str(tmp_path / "out")], input=fa, capture_output=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "out_1.fa").read_bytes() == b">a1 x 3:sub:A-C \nACCTAC\n>a2  \nGG\n"
+    assert (tmp_path / "out_2.fa").read_bytes() == b">b1\nN\n>b2 y  \nCC\n"
