@@ -93,9 +93,7 @@ __device__ __forceinline__ void ec_replace0(ec_mer& m, int k, uint32_t y) {  // 
 }
 // hash of mer.canonical() (kmer.hpp:43): position and remainder of the key in any table of this k
 __device__ __forceinline__ uint64_t ec_hash(const ec_mer& m, int k) {
-  uint32_t c0, c1;
-  qh_canonical_planes(m.a0, m.a1, m.b0, m.b1, &c0, &c1);
-  return qh_mix_pair(c0, c1, m.a0 ^ m.b0 ^ c0, m.a1 ^ m.b1 ^ c1, k);
+  return qh_hash_strands(m.a0, m.a1, m.b0, m.b1, k);
 }
 __device__ __forceinline__ uint32_t ec_code0(const ec_mer& m) { return (m.a0 & 1u) | ((m.a1 & 1u) << 1); }
 

@@ -275,10 +275,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
             const uint32_t q = ((uint32_t)(wh >> j) & kones) == kones;         // high_len >= k (:86)
             const uint32_t r0 = ~(uint32_t)(w0 >> j) & kones, r1 = ~(uint32_t)(w1 >> j) & kones;
             const uint32_t m0 = (uint32_t)(f0 >> (QP_SEG - 1 - j)) & kones, m1 = (uint32_t)(f1 >> (QP_SEG - 1 - j)) & kones;
-            uint32_t c0, c1;
-            qh_canonical_planes(m0, m1, r0, r1, &c0, &c1);
-            // both orientations are at hand: the hash takes the smaller core of the two (qh_spec.h)
-            const uint64_t h = qh_mix_pair(c0, c1, m0 ^ r0 ^ c0, m1 ^ r1 ^ c1, g.k);
+            const uint64_t h = qh_hash_strands(m0, m1, r0, r1, g.k);  // min(m, rm) of create_database.cc:86, hashed
             if (p.check_owner && ((uint32_t)h & smask) != (uint32_t)g.shard_id) {
               ++n_foreign;
             } else {
