@@ -182,6 +182,32 @@ def test_contaminant(trim):
     gc.close(); q.close(); h.close(); odb.close(); oc.close()
 
 
+def test_config5_shape_k31_paired_tails_adapters():
+    """BASELINE configs[4]: 150 bp reads, 3 % errors, low-quality tails, k = 31, adapters spliced at the 3' end
+    of 1 % of the reads, contaminant set = data/adapter.fa, --trim-contaminant (64-bit tags: the wide kernel)"""
+    k = 31
+    rng = np.random.default_rng(55)
+    g = synth.make_genome(40000, seed=51)
+    fq = synth.make_fastq(g, 10000, 150, err=0.03, seed=52, tails=True).tobytes()
+    adapters = [l.strip() for l in open(ADAPTERS, "rb").read().split(b"\n") if l and not l.startswith(b">")]
+    adapters = [a for a in adapters if len(a) >= k]
+    recs = fq.split(b"\n")
+    for i in range(1, len(recs), 4):
+        if rng.random() < 0.01:
+            a = adapters[int(rng.integers(0, len(adapters)))]
+            n = min(len(a), 60)
+            recs[i] = recs[i][:150 - n] + a[:n]
+    fq = b"\n".join(recs)
+    odb, h, q = build_pair(fq, k, size=1 << 22)
+    oc = po.OracleDB(1 << 16, k, 1)
+    oc.add_fasta(open(ADAPTERS, "rb").read())
+    gc = qa.contaminant_database(ADAPTERS, k)
+    fa, lg, st = check_parity(odb, q, fq, ocont=oc, gcont=gc, trim_contaminant=True, via="device")
+    assert st["truncations"] > 50 and st["substitutions"] > 10000
+    check_parity(odb, q, fq, ocont=oc, gcont=gc, trim_contaminant=False, homo_trim=3, no_discard=True)
+    gc.close(); q.close(); h.close(); odb.close(); oc.close()
+
+
 def test_multiline_records_take_the_host_parser():
     g = synth.make_genome(8000, seed=2)
     fq = synth.make_fastq(g, 1500, 100, err=0.01, seed=4).tobytes()
