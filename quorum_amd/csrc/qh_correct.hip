@@ -312,6 +312,50 @@ __device__ __forceinline__ W ec_sel4(const W (&c)[4], int i) {
   return i == 0 ? c[0] : i == 1 ? c[1] : i == 2 ? c[2] : c[3];
 }
 
+// database_query::get_best_alternatives batched (qh_query_best_alternatives_batch): a mer per lane, the
+// four siblings in one walk. fmers are 2-bit packed forward mers; backward[i] selects backward_mer.
+template <bool NARROW>
+__global__ __launch_bounds__(256) void k_best_alternatives_sib(const uint64_t* __restrict__ table, const qh_geom g,
+                                                               const uint64_t* __restrict__ fmers,
+                                                               const uint8_t* __restrict__ backward, uint64_t n,
+                                                               uint64_t* __restrict__ counts, int32_t* __restrict__ ucode,
+                                                               int32_t* __restrict__ level, int32_t* __restrict__ nkept) {
+  typedef typename ec_word<NARROW>::type W;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t pk = qh_pkey(fmers[i] & g.kmask, g.k);
+    const uint32_t km = (uint32_t)((1ull << g.k) - 1);
+    const uint32_t f0 = (uint32_t)pk & km, f1 = (uint32_t)(pk >> g.k) & km;
+    uint32_t r0, r1;
+    qh_rc_planes(f0, f1, g.k, &r0, &r1);
+    const int d = backward[i] ? -1 : +1;
+    const ec_mer m = d > 0 ? ec_mer{f0, f1, r0, r1} : ec_mer{r0, r1, f0, f1};
+    W c[4];
+    int uc = 0, lvl = 0;
+    const int cnt = ec_best_alternatives<NARROW, true>(g, table, m, d, c, &uc, &lvl);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) counts[i * 4 + a] = c[a];
+    ucode[i] = uc; level[i] = lvl; nkept[i] = cnt;
+  }
+}
+
+void qh_launch_best_alternatives(const uint64_t* table, const qh_geom& g, const uint64_t* fmers, const uint8_t* backward,
+                                 uint64_t n, uint64_t* counts, int32_t* ucode, int32_t* level, int32_t* nkept,
+                                 hipStream_t s) {
+  if (!n) return;
+  if (!(g.k >= 4 && g.wbits >= 3 && g.lsize + g.shard_bits <= 2 * (g.k - 2))) {
+    qh_launch_best_alternatives_generic(table, g, fmers, backward, n, counts, ucode, level, nkept, s);
+    return;
+  }
+  uint64_t blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  if (g.vbits <= 32 && g.rbits + g.pbits <= 32)
+    hipLaunchKernelGGL(k_best_alternatives_sib<true>, dim3((unsigned)blocks), dim3(256), 0, s, table, g, fmers, backward, n,
+                       counts, ucode, level, nkept);
+  else
+    hipLaunchKernelGGL(k_best_alternatives_sib<false>, dim3((unsigned)blocks), dim3(256), 0, s, table, g, fmers, backward, n,
+                       counts, ucode, level, nkept);
+}
+
 // ------------------------------------------------------------------ err_log
 
 // entry: pos (24 bits) | type << 24 (0 substitution, 1 truncation) | from << 25 | to << 28 (0..3, 4 = 'N')

@@ -103,9 +103,13 @@ void qh_launch_lookup(const uint64_t* table, const qh_geom& g, const uint64_t* m
 // out may be null (membership only); the two tables share k
 void qh_launch_lookup_contaminant(const uint64_t* table, const qh_geom& g, const uint64_t* ctable, const qh_geom& cg,
                                   const uint64_t* mers, uint64_t n, uint64_t* out, uint8_t* flags, hipStream_t s);
+// (qh_correct.hip: one walk for the four siblings where the geometry allows it, else the generic kernel)
 void qh_launch_best_alternatives(const uint64_t* table, const qh_geom& g, const uint64_t* fmers,
                                  const uint8_t* backward, uint64_t n, uint64_t* counts,
                                  int32_t* ucode, int32_t* level, int32_t* nkept, hipStream_t s);
+void qh_launch_best_alternatives_generic(const uint64_t* table, const qh_geom& g, const uint64_t* fmers,
+                                         const uint8_t* backward, uint64_t n, uint64_t* counts,
+                                         int32_t* ucode, int32_t* level, int32_t* nkept, hipStream_t s);
 void qh_launch_stats(const uint64_t* table, const qh_geom& g, qh_meta* meta, hipStream_t s);
 void qh_launch_histo(const uint64_t* table, const qh_geom& g, unsigned long long* histo, hipStream_t s);
 void qh_launch_dump(const uint64_t* table, const qh_geom& g, uint64_t* mers, uint64_t* vals,

@@ -399,9 +399,10 @@ __global__ __launch_bounds__(QH_BLOCK) void k_best_alternatives(const uint64_t* 
   }
 }
 
-void qh_launch_best_alternatives(const uint64_t* table, const qh_geom& g, const uint64_t* fmers,
-                                 const uint8_t* backward, uint64_t n, uint64_t* counts, int32_t* ucode,
-                                 int32_t* level, int32_t* nkept, hipStream_t s) {
+// tables whose home slot may depend on the end bases (tiny k or tiny tables): four independent lookups
+void qh_launch_best_alternatives_generic(const uint64_t* table, const qh_geom& g, const uint64_t* fmers,
+                                         const uint8_t* backward, uint64_t n, uint64_t* counts, int32_t* ucode,
+                                         int32_t* level, int32_t* nkept, hipStream_t s) {
   if (!n) return;
   hipLaunchKernelGGL(k_best_alternatives, dim3(grid_for(n * 4, QH_BLOCK, 8192)), dim3(QH_BLOCK), 0, s, table, g,
                      fmers, backward, n, counts, ucode, level, nkept);
