@@ -22,3 +22,16 @@ for it in range(3):
 kmers = int(r.stderr.split("k-mers")[1].split()[0])
 print(json.dumps({"fastq_bytes": int(fq.size), "kmers": kmers, "wall_s": res, "best_kmers_per_s": kmers / min(res),
                   "db_bytes": os.path.getsize(out), "stderr": r.stderr.strip()}))
+
+# the corrector on the same file and database (src/quorum.in:160-171)
+ec = os.path.join(ROOT, "quorum_amd", "bin", "quorum_error_correct_reads")
+eres = []
+for it in range(3):
+    t0 = time.time()
+    r = subprocess.run([ec, "-v", out, "-o", "/tmp/cli_bench_ec", path], capture_output=True, text=True)
+    dt = time.time() - t0
+    assert r.returncode == 0, r.stderr
+    eres.append(dt)
+print(json.dumps({"tool": "quorum_error_correct_reads", "reads": 2_000_000, "wall_s": eres,
+                  "best_bases_per_s": 200_000_000 / min(eres), "fa_bytes": os.path.getsize("/tmp/cli_bench_ec.fa"),
+                  "stderr": r.stderr.strip().splitlines()}))
