@@ -616,147 +616,161 @@ __global__ __launch_bounds__(EC_BLOCK) __attribute__((amdgpu_waves_per_eu(EC_WAV
       uint32_t prev_count = prev0;
       // the character under the head is loaded one step ahead: it never waits behind the lookups
       uint8_t nbase = ip != end ? ec_read(rb, buf, buf_len, rc.x + (uint32_t)ip) : (uint8_t)0;
+      // A base normally costs one iteration: shift, one sibling walk, decide. Where several alternatives
+      // survive (error_correct_reads.cc:464-560) each candidate needs the walk of ITS continuation; instead of
+      // a second walk nested in the step -- which the whole wave would execute whenever one lane needs it,
+      // about every other step -- the lane stays on the base (in_cont) and spends its next iterations on
+      // the candidates through the SAME walk code the other lanes use for their next bases.
+      bool in_cont = false;
+      uint32_t qm = 0, succ = 0, cwcb = 0;  // candidates left / that continue / that continue with the read's next base
+      W s_counts[4] = {0, 0, 0, 0};         // the base's counts while its candidates are looked up
+      int s_level = 0, check_code = 0, ori_code = 0, cpos = 0, cur_i = 0;
       for (;;) {
-        bool fin = ip == end;
-        if (!fin) {
-          const uint8_t base = nbase;
-          nbase = ip + d != end ? ec_read(rb, buf, buf_len, rc.x + (uint32_t)(ip + d)) : (uint8_t)0;
-          if (base == '\n') { ip += d; continue; }
-          const int cpos = pos;
-          pos += d;
-          const int ori_code = qh_code(base);
-          const uint32_t x = ori_code >= 0 ? (uint32_t)ori_code : 0u;
-          ec_shift(mer, k, km, d > 0 ? x : 3u - x);
-          bool emit = false;
-          if (ori_code >= 0 && ctable) {
-            const int cc = ec_check_contaminant<NARROW>(P, ctable, mer, log, cpos);
-            if (cc == EC_TRUNCATE) fin = true;
-            else if (cc == EC_ERROR) { status = EC_ST_CONTAMINANT; break; }
-          }
+        bool fin = false, emit = false, finalize = false, lookup = false;
+        ec_mer lm = mer;
+        if (!in_cont) {
+          fin = ip == end;
           if (!fin) {
-            W counts[4];
-            int ucode = 0, level;
-            const int count = ec_best_alternatives<NARROW, SIB>(P.g, table, mer, d, counts, &ucode, &level);
-            if (count == 1 && ucode == ori_code) {  // the read's base is the one continuation: the common case
-              prev_count = (uint32_t)ec_sel4(counts, ucode);
-              emit = true;
-            } else if (count == 0) {  // no continuation whatsoever
-              ec_truncation(log, cpos, P.window, P.error);
-              fin = true;
-            } else if (count == 1) {  // one continuation: a substitution
-              prev_count = (uint32_t)ec_sel4(counts, ucode);
-              const int lc = ec_log_substitution<NARROW>(P, ctable, mer, d, out, log, cpos, ori_code, ucode);
-              if (lc == EC_TRUNCATE) fin = true;
-              else if (lc == EC_ERROR) { status = EC_ST_CONTAMINANT; break; }
-              else emit = true;
-            } else {
-              bool multi = true;
-              if (ori_code >= 0) {
-                const uint64_t co = ec_sel4(counts, ori_code);
-                if (co > (uint64_t)P.min_count) {
-                  if (co >= (uint32_t)P.cutoff || (int)(int8_t)buf[rc.z + (uint32_t)ip] >= (int)(int8_t)P.qual_cutoff) {
-                    emit = true; multi = false;
+            const uint8_t base = nbase;
+            nbase = ip + d != end ? ec_read(rb, buf, buf_len, rc.x + (uint32_t)(ip + d)) : (uint8_t)0;
+            if (base == '\n') { ip += d; continue; }
+            cpos = pos;
+            pos += d;
+            ori_code = qh_code(base);
+            const uint32_t x = ori_code >= 0 ? (uint32_t)ori_code : 0u;
+            ec_shift(mer, k, km, d > 0 ? x : 3u - x);
+            if (ori_code >= 0 && ctable) {
+              const int cc = ec_check_contaminant<NARROW>(P, ctable, mer, log, cpos);
+              if (cc == EC_TRUNCATE) fin = true;
+              else if (cc == EC_ERROR) { status = EC_ST_CONTAMINANT; break; }
+            }
+            lm = mer;
+            lookup = !fin;
+          }
+        } else {  // the continuation of candidate cur_i: nmer.replace(0, i); nmer.shift(0) (:492-496)
+          cur_i = __ffs((int)qm) - 1;
+          qm &= qm - 1u;
+          ec_replace0(lm, k, (uint32_t)(d > 0 ? cur_i : 3 - cur_i));
+          ec_shift(lm, k, km, d > 0 ? 0u : 3u);
+          lookup = true;
+        }
+        const bool stepping = lookup || fin;  // an iteration that works on a base (fin: cut short before its lookup)
+        W counts[4] = {0, 0, 0, 0};
+        int ucode = 0, level = 0, count = 0;
+        if (lookup) count = ec_best_alternatives<NARROW, SIB>(P.g, table, lm, d, counts, &ucode, &level);
+        if (lookup && in_cont) {
+          check_code = cur_i;
+          if (count > 0 && level >= s_level) {  // :502-506
+            const int rn = ip + d != end ? qh_code(nbase) : -1;
+            if (rn >= 0 && ec_sel4(counts, rn) > 0) cwcb |= 1u << cur_i;
+            succ |= 1u << cur_i;
+          }
+          if (!qm) { in_cont = false; finalize = true; }
+        } else if (lookup) {
+          if (count == 1 && ucode == ori_code) {  // the read's base is the one continuation: the common case
+            prev_count = (uint32_t)ec_sel4(counts, ucode);
+            emit = true;
+          } else if (count == 0) {  // no continuation whatsoever
+            ec_truncation(log, cpos, P.window, P.error);
+            fin = true;
+          } else if (count == 1) {  // one continuation: a substitution
+            prev_count = (uint32_t)ec_sel4(counts, ucode);
+            const int lc = ec_log_substitution<NARROW>(P, ctable, mer, d, out, log, cpos, ori_code, ucode);
+            if (lc == EC_TRUNCATE) fin = true;
+            else if (lc == EC_ERROR) { status = EC_ST_CONTAMINANT; break; }
+            else emit = true;
+          } else {
+            bool multi = true;
+            if (ori_code >= 0) {
+              const uint64_t co = ec_sel4(counts, ori_code);
+              if (co > (uint64_t)P.min_count) {
+                if (co >= (uint32_t)P.cutoff || (int)(int8_t)buf[rc.z + (uint32_t)ip] >= (int)(int8_t)P.qual_cutoff) {
+                  emit = true; multi = false;
+                } else {
+                  const uint64_t sum = (uint64_t)counts[0] + counts[1] + counts[2] + counts[3];
+                  bool keep;
+                  if (P.ptab_stride) {
+                    const uint64_t bit = co * (uint64_t)P.ptab_stride + sum;
+                    keep = (ptab[bit >> 5] >> (bit & 31)) & 1u;
                   } else {
-                    const uint64_t sum = (uint64_t)counts[0] + counts[1] + counts[2] + counts[3];
-                    bool keep;
-                    if (P.ptab_stride) {
-                      const uint64_t bit = co * (uint64_t)P.ptab_stride + sum;
-                      keep = (ptab[bit >> 5] >> (bit & 31)) & 1u;
-                    } else {
-                      keep = ec_poisson_term((double)sum * P.collision_prob, (unsigned)co) < P.poisson_threshold;
-                    }
-                    if (keep) { emit = true; multi = false; }
+                    keep = ec_poisson_term((double)sum * P.collision_prob, (unsigned)co) < P.poisson_threshold;
                   }
-                } else if (level == 0 && co == 0) {  // an error and all alternatives are low quality
-                  ec_truncation(log, cpos, P.window, P.error);
-                  fin = true; multi = false;
+                  if (keep) { emit = true; multi = false; }
                 }
-              } else if (level == 0) {  // N and all alternatives are low quality
+              } else if (level == 0 && co == 0) {  // an error and all alternatives are low quality
                 ec_truncation(log, cpos, P.window, P.error);
                 fin = true; multi = false;
               }
-              if (multi) {  // several possible substitutions (error_correct_reads.cc:464-560)
-                int check_code = ori_code;
-                bool success = false;
-                W cont_counts[4] = {0, 0, 0, 0};
-                uint32_t cwcb = 0;  // continue_with_correct_base, one bit per code
-                const int read_nbase_code = ip + d != end ? qh_code(nbase) : -1;
-                // upstream walks i = 0..3 and skips counts[i] <= min_count; here every lane walks ITS
-                // qualifying codes in ascending order, so the wave makes as many extra lookups as its
-                // busiest lane has candidates (usually one) instead of four
-                uint32_t qm = 0;
+            } else if (level == 0) {  // N and all alternatives are low quality
+              ec_truncation(log, cpos, P.window, P.error);
+              fin = true; multi = false;
+            }
+            if (multi) {  // several possible substitutions: look the candidates' continuations up first
+              check_code = ori_code;
+              succ = 0; cwcb = 0; s_level = level;
+              qm = 0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) qm |= (uint32_t)((uint64_t)counts[i] > (uint64_t)P.min_count) << i;
-#pragma unroll 1
-                while (qm) {
-                  const int i = __ffs((int)qm) - 1;
-                  qm &= qm - 1u;
-                  const W ci = ec_sel4(counts, i);
-                  check_code = i;
-                  ec_mer nmer = mer;
-                  ec_replace0(nmer, k, (uint32_t)(d > 0 ? i : 3 - i));
-                  ec_shift(nmer, k, km, d > 0 ? 0u : 3u);
-                  W ncounts[4];
-                  int nucode = 0, nlevel;
-                  const int ncount = ec_best_alternatives<NARROW, SIB>(P.g, table, nmer, d, ncounts, &nucode, &nlevel);
-                  if (ncount > 0 && nlevel >= level) {
-                    if (read_nbase_code >= 0 && ec_sel4(ncounts, read_nbase_code) > 0) cwcb |= 1u << i;
-                    success = true;
-                    if (i == 0) cont_counts[0] = ci; else if (i == 1) cont_counts[1] = ci;
-                    else if (i == 2) cont_counts[2] = ci; else cont_counts[3] = ci;
-                  }
-                }
-                if (success) {
-                  check_code = -1;
-                  const uint32_t pc = prev_count <= (uint64_t)P.min_count ? 0xFFFFFFFFu : prev_count;
-                  int min_diff = INT_MAX;
-                  uint32_t cand = 0;
-                  unsigned ncand = 0;
-#pragma unroll
-                  for (int i = 0; i < 4; ++i)
-                    if (cont_counts[i] > 0) {
-                      const long long ad = llabs((long long)cont_counts[i] - (long long)pc);
-                      const int dd = (int)ad;  // upstream's (int) cast, :521
-                      if (dd < min_diff) min_diff = dd;
-                    }
-#pragma unroll
-                  for (int i = 0; i < 4; ++i)
-                    if (llabs((long long)cont_counts[i] - (long long)pc) == (long long)min_diff) {  // :526
-                      cand |= 1u << i; ++ncand; check_code = i;
-                    }
-                  if (ncand > 1 && read_nbase_code >= 0) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                      if ((cand >> i) & 1u) {
-                        if (!((cwcb >> i) & 1u)) --ncand;
-                        else check_code = i;
-                      }
-                  }
-                  if (ncand != 1) check_code = -1;
-                  if (check_code >= 0) {
-                    const int lc = ec_log_substitution<NARROW>(P, ctable, mer, d, out, log, cpos, ori_code, check_code);
-                    if (lc == EC_TRUNCATE) fin = true;
-                    else if (lc == EC_ERROR) { status = EC_ST_CONTAMINANT; break; }
-                  }
-                }
-                if (!fin) {
-                  if (ori_code < 0 && check_code < 0) {  // invalid base and no good substitution
-                    ec_truncation(log, cpos, P.window, P.error);
-                    fin = true;
-                  } else {
-                    emit = true;
-                  }
-                }
+              for (int i = 0; i < 4; ++i) {
+                s_counts[i] = counts[i];
+                qm |= (uint32_t)((uint64_t)counts[i] > (uint64_t)P.min_count) << i;  // :488-489
               }
+              if (qm) in_cont = true;
+              else finalize = true;
             }
           }
-          if (emit) {  // *out++ = mer.base(0)
-            const uint32_t c0 = ec_code0(mer);
-            ec_write(wb, obuf, rc.x + (uint32_t)out, (uint8_t)(0x54474341u >> (8u * (d > 0 ? c0 : 3u - c0)))  /* "ACGT"[code] */);
-            out += d;
-          }
-          ip += d;
         }
+        if (finalize) {  // :509-560 once every candidate has been looked up
+          if (succ) {
+            check_code = -1;
+            const int rn = ip + d != end ? qh_code(nbase) : -1;
+            const uint32_t pc = prev_count <= (uint64_t)P.min_count ? 0xFFFFFFFFu : prev_count;
+            int min_diff = INT_MAX;
+            uint32_t cand = 0;
+            unsigned ncand = 0;
+            long long ad[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const long long cc = (succ >> i) & 1u ? (long long)s_counts[i] : 0ll;  // cont_counts[i]
+              ad[i] = llabs(cc - (long long)pc);
+              if (cc > 0) {
+                const int dd = (int)ad[i];  // upstream's (int) cast, :521
+                if (dd < min_diff) min_diff = dd;
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (ad[i] == (long long)min_diff) { cand |= 1u << i; ++ncand; check_code = i; }  // :526
+            if (ncand > 1 && rn >= 0) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                if ((cand >> i) & 1u) {
+                  if (!((cwcb >> i) & 1u)) --ncand;
+                  else check_code = i;
+                }
+            }
+            if (ncand != 1) check_code = -1;
+            if (check_code >= 0) {
+              const int lc = ec_log_substitution<NARROW>(P, ctable, mer, d, out, log, cpos, ori_code, check_code);
+              if (lc == EC_TRUNCATE) fin = true;
+              else if (lc == EC_ERROR) { status = EC_ST_CONTAMINANT; break; }
+            }
+          }
+          if (!fin) {
+            if (ori_code < 0 && check_code < 0) {  // invalid base and no good substitution
+              ec_truncation(log, cpos, P.window, P.error);
+              fin = true;
+            } else {
+              emit = true;
+            }
+          }
+        }
+        if (emit) {  // *out++ = mer.base(0)
+          const uint32_t c0 = ec_code0(mer);
+          ec_write(wb, obuf, rc.x + (uint32_t)out, (uint8_t)(0x54474341u >> (8u * (d > 0 ? c0 : 3u - c0)))  /* "ACGT"[code] */);
+          out += d;
+        }
+        if (lookup && !in_cont) ip += d;  // the base is done
+        (void)stepping;
         if (fin) {
           if (d > 0) {
             end_out = out;
