@@ -180,3 +180,47 @@ def test_paired_end_pipeline(tmp_path):
     assert (tmp_path / "p_2.fa").read_bytes() == want2
     assert (tmp_path / "p.log").read_bytes() == lg
     assert (tmp_path / "p_1.fa").read_bytes().count(b">") == 6000
+
+
+def test_quorum_driver(tmp_path):
+    """the driver (src/quorum.in): min-q-char autodetection, database, correction; -P keeps mates in two files"""
+    import sys
+    drv = [sys.executable, os.path.join(ROOT, "quorum_amd", "quorum_driver.py")]
+    k = 24
+    g = synth.make_genome(30000, seed=61)
+    fq1 = synth.make_fastq(g, 5000, 100, seed=62, tails=True).tobytes()
+    fq2 = synth.make_fastq(g, 5000, 100, seed=63, tails=True, first_id=5000).tobytes()
+    (tmp_path / "r1.fastq").write_bytes(fq1)
+    (tmp_path / "r2.fastq").write_bytes(fq2)
+    prefix = str(tmp_path / "qc")
+    r = subprocess.run(drv + ["-s", "1M", "-p", prefix, "--debug", str(tmp_path / "r1.fastq"), str(tmp_path / "r2.fastq")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "-q 38 -b 7" in r.stderr                      # detected 33 ('#' = 35 -> 33), + min-quality 5 (quorum.in:146,156)
+    db = po.OracleDB(1 << 20, k, 7)
+    db.add_fastq(fq1, 38)
+    db.add_fastq(fq2, 38)
+    cut = db.poisson_cutoff(0.01 / 3, 1e-6 / 0.01)
+    fa1, lg1, _ = db.correct_fastq(fq1, po.ec_params(cut))
+    fa2, lg2, _ = db.correct_fastq(fq2, po.ec_params(cut))
+    assert open(prefix + ".fa", "rb").read() == fa1 + fa2 and open(prefix + ".log", "rb").read() == lg1 + lg2
+    assert os.path.exists(prefix + "_mer_database.jf")
+    # paired files, window / error / homo-trim passed through, -d implied
+    r = subprocess.run(drv + ["-s", "1M", "-p", prefix, "-P", "-w", "8", "-e", "2", "--homo-trim", "3",
+                              str(tmp_path / "r1.fastq"), str(tmp_path / "r2.fastq")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    l1, l2 = fq1.split(b"\n"), fq2.split(b"\n")
+    inter = b"".join(b"\n".join(l1[i:i + 4]) + b"\n" + b"\n".join(l2[i:i + 4]) + b"\n" for i in range(0, len(l1) - 1, 4))
+    fa, lg, n = db.correct_fastq(inter, po.ec_params(cut, window=8, error=2, homo_trim=3, no_discard=True))
+    out = fa.split(b"\n")
+    assert open(prefix + "_1.fa", "rb").read() == b"".join(out[i] + b"\n" + out[i + 1] + b"\n" for i in range(0, len(out) - 1, 4))
+    assert open(prefix + "_2.fa", "rb").read() == b"".join(out[i + 2] + b"\n" + out[i + 3] + b"\n" for i in range(0, len(out) - 1, 4))
+    assert open(prefix + ".log", "rb").read() == lg
+    # argument rules (:92-99)
+    r = subprocess.run(drv + ["-s", "12x", "f"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Invalid size '12x'" in r.stderr
+    r = subprocess.run(drv + ["-s", "1M"], capture_output=True, text=True)
+    assert r.returncode == 1 and "No sequence files" in r.stderr
+    (tmp_path / "odd.fastq").write_bytes(b"@r\nACGT\n+\nKKKK\n")   # minimum quality 'K' = 75: not a known offset
+    r = subprocess.run(drv + ["-s", "1M", str(tmp_path / "odd.fastq")], capture_output=True, text=True)
+    assert r.returncode == 1 and "unusual minimum quality char" in r.stderr
