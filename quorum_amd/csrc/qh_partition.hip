@@ -637,33 +637,17 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
 __global__ __launch_bounds__(QP_THREADS) void k_window_count(uint64_t* __restrict__ table, const qh_geom g,
                                                              const uint64_t* __restrict__ items, uint64_t cap,
                                                              const unsigned long long* __restrict__ counts,
-                                                             int table_dirty, uint64_t* __restrict__ spill,
-                                                             uint64_t spill_cap, qh_meta* __restrict__ meta, int cb) {
+                                                             uint32_t n_windows, int table_dirty,
+                                                             uint64_t* __restrict__ spill, uint64_t spill_cap,
+                                                             qh_meta* __restrict__ meta, int cb) {
   __shared__ uint64_t win[1u << QH_WINDOW_BITS];
   __shared__ uint64_t ring[QP_WAVES][QW_RING];
   __shared__ uint32_t wnew[QP_WAVES];
-  const uint32_t w = blockIdx.x;
-  uint64_t n = counts[w];
-  if (n > cap) n = cap;
-  if (n == 0) {  // nothing to add: the window stays as it is, or is cleared when the table's clearing was left to us
-    if (table_dirty & 2) {
-      uint4* z = reinterpret_cast<uint4*>(table + ((uint64_t)w << QH_WINDOW_BITS));
-      for (uint32_t i = threadIdx.x; i < (1u << QH_WINDOW_BITS) / 2; i += QP_THREADS) z[i] = make_uint4(0, 0, 0, 0);
-    }
-    return;
-  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint32_t seg = (uint32_t)((n + QP_WAVES - 1) / QP_WAVES);
-  const uint32_t s0 = (uint32_t)(((uint64_t)wave * seg) < n ? (uint64_t)wave * seg : n);
-  const uint32_t seg_n = (uint32_t)((uint64_t)s0 + seg <= n ? seg : n - s0);
-  const uint64_t* src = items + (uint64_t)w * cap + s0;
-  uint64_t pend = (uint32_t)lane < seg_n ? src[lane] : QP_NONE;
-  bool pending = seg_n > 0;
 
   const int tagshift = 2 * cb;  // >= 32
   const uint64_t cmask = (1ull << cb) - 1, hinc = 1ull << cb;
-  uint4* tw = reinterpret_cast<uint4*>(table + ((uint64_t)w << QH_WINDOW_BITS));
   uint4* lw = reinterpret_cast<uint4*>(win);
   const uint32_t nvec = (1u << QH_WINDOW_BITS) / 2;  // 16-byte pieces
   auto to_counting = [&](uint64_t slot) -> uint64_t {
@@ -676,114 +660,153 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_count(uint64_t* __restric
     const uint64_t v = ((c < g.max_val ? c : g.max_val) << 1) | (hc ? 1u : 0u);
     return t ? (t << g.vbits) | v : 0ull;
   };
-  if (table_dirty & 1) {
-#pragma unroll
-    for (uint32_t i = 0; i < nvec / QP_THREADS; ++i) {
-      const uint4 x = tw[i * QP_THREADS + tid];
-      const uint64_t a = to_counting(((uint64_t)x.y << 32) | x.x), b = to_counting(((uint64_t)x.w << 32) | x.z);
-      lw[i * QP_THREADS + tid] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
-    }
-  } else {
-#pragma unroll
-    for (uint32_t i = 0; i < nvec / QP_THREADS; ++i) lw[i * QP_THREADS + tid] = make_uint4(0, 0, 0, 0);
-  }
-  __syncthreads();
-
   const int gsize = g.lsize + g.shard_bits;
   const uint32_t wmask = (1u << QH_WINDOW_BITS) - 1;
   uint64_t* myring = ring[wave];
-  uint32_t head = 0, tail = 0, head_mod = 0, tail_mod = 0;  // wave-uniform ring state (see k_window_build)
   uint32_t n_new = 0;
-  bool live = false;
-  uint32_t T = 0, pos = 0, left = 0, q = 0;  // chain state: tag at this probe, position, probes left, quality
 
-  for (;;) {
-    uint32_t avail = tail - head;
-    if (pending && avail < 64) {
-      // decoded once, with every lane busy: {position | q << 16, tag at probe 0}
-      const uint64_t h = pend >> 1;
-      const uint32_t p0 = (uint32_t)(h >> g.shard_bits) & wmask;
-      const uint32_t t0 = ((uint32_t)(gsize >= 64 ? 0 : (h >> gsize)) << g.pbits) | 1u;
-      uint32_t at = tail_mod + lane;
-      if (at >= QW_RING) at -= QW_RING;
-      myring[at] = ((uint64_t)t0 << 32) | p0 | (((uint32_t)pend & 1u) << 16);
-      const uint32_t got = seg_n - tail < 64 ? seg_n - tail : 64;
-      tail += got;
-      tail_mod += got;
-      if (tail_mod >= QW_RING) tail_mod -= QW_RING;
-      pending = false;
-      avail = tail - head;
+  // The workgroup walks windows blockIdx.x, + gridDim.x, ... (one workgroup per CU: the window fills its LDS), so
+  // that what a fresh workgroup would wait for is requested a window ahead: the next bucket's size while this
+  // window is counted, the first items of this wave's segment of it before this window is written out.
+  uint32_t seg_n = 0;             // this wave's segment of the bucket: src[0 .. seg_n)
+  const uint64_t* src = items;
+  uint64_t pend = QP_NONE;        // its first 64 items, requested
+  auto open_bucket = [&](uint32_t w, uint64_t n) {
+    const uint32_t seg = (uint32_t)((n + QP_WAVES - 1) / QP_WAVES);
+    const uint32_t s0 = (uint32_t)(((uint64_t)wave * seg) < n ? (uint64_t)wave * seg : n);
+    seg_n = (uint32_t)((uint64_t)s0 + seg <= n ? seg : n - s0);
+    src = items + (uint64_t)w * cap + s0;
+    pend = (uint32_t)lane < seg_n ? src[lane] : QP_NONE;
+  };
+  auto bucket_size = [&](uint32_t w) -> uint64_t {
+    if (w >= n_windows) return 0;
+    const uint64_t n = counts[w];
+    return n > cap ? cap : n;
+  };
+  uint32_t w = blockIdx.x;
+  uint64_t n = bucket_size(w);
+  open_bucket(w, n);
+
+  for (; w < n_windows; w += gridDim.x) {
+    const uint64_t n_next = bucket_size(w + gridDim.x);
+    uint4* tw = reinterpret_cast<uint4*>(table + ((uint64_t)w << QH_WINDOW_BITS));
+    if (n == 0) {  // nothing to add: the window stays as it is, or is cleared when the table's clearing was left to us
+      if (table_dirty & 2)
+        for (uint32_t i = tid; i < nvec; i += QP_THREADS) tw[i] = make_uint4(0, 0, 0, 0);
+      n = n_next;
+      open_bucket(w + gridDim.x, n);
+      continue;
     }
-    if (!pending && tail < seg_n && avail <= QW_RING - 64) {
-      pend = tail + lane < seg_n ? src[tail + lane] : QP_NONE;
-      pending = true;
+    // every thread fills the pieces of the window it wrote out for the previous one: no barrier in between
+    if (table_dirty & 1) {
+#pragma unroll
+      for (uint32_t i = 0; i < nvec / QP_THREADS; ++i) {
+        const uint4 x = tw[i * QP_THREADS + tid];
+        const uint64_t a = to_counting(((uint64_t)x.y << 32) | x.x), b = to_counting(((uint64_t)x.w << 32) | x.z);
+        lw[i * QP_THREADS + tid] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+      }
+    } else {
+#pragma unroll
+      for (uint32_t i = 0; i < nvec / QP_THREADS; ++i) lw[i * QP_THREADS + tid] = make_uint4(0, 0, 0, 0);
     }
-    __builtin_amdgcn_wave_barrier();
-    const uint64_t need = __ballot(!live);
-    if (need == ~0ull && avail == 0 && !pending && head == seg_n) break;
-    if (need && avail) {
-      const uint32_t cnt = (uint32_t)__popcll((unsigned long long)need);
-      const uint32_t give = cnt < avail ? cnt : avail;
-      const uint32_t rank = lanes_below(need);
-      if (!live && rank < give) {
-        uint32_t at = head_mod + rank;
+    __syncthreads();
+
+    uint32_t head = 0, tail = 0, head_mod = 0, tail_mod = 0;  // wave-uniform ring state (see k_window_build)
+    bool pending = seg_n > 0;
+    bool live = false;
+    uint32_t T = 0, pos = 0, left = 0, q = 0;  // chain state: tag at this probe, position, probes left, quality
+
+    for (;;) {
+      uint32_t avail = tail - head;
+      if (pending && avail < 64) {
+        // decoded once, with every lane busy: {position | q << 16, tag at probe 0}
+        const uint64_t h = pend >> 1;
+        const uint32_t p0 = (uint32_t)(h >> g.shard_bits) & wmask;
+        const uint32_t t0 = ((uint32_t)(gsize >= 64 ? 0 : (h >> gsize)) << g.pbits) | 1u;
+        uint32_t at = tail_mod + lane;
         if (at >= QW_RING) at -= QW_RING;
-        const uint64_t e = __hip_atomic_load(&myring[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        T = (uint32_t)(e >> 32);
-        pos = (uint32_t)e & wmask;
-        q = ((uint32_t)e >> 16) & 1u;
-        left = (uint32_t)g.max_reprobe;
-        live = true;
+        myring[at] = ((uint64_t)t0 << 32) | p0 | (((uint32_t)pend & 1u) << 16);
+        const uint32_t got = seg_n - tail < 64 ? seg_n - tail : 64;
+        tail += got;
+        tail_mod += got;
+        if (tail_mod >= QW_RING) tail_mod -= QW_RING;
+        pending = false;
+        avail = tail - head;
       }
-      head += give;
-      head_mod += give;
-      if (head_mod >= QW_RING) head_mod -= QW_RING;
-    }
-    if (live) {
-      unsigned long long* slot = reinterpret_cast<unsigned long long*>(&win[pos]);
-      const uint64_t inc = q ? hinc : 1ull;
-      const uint64_t old = atomicAdd(slot, (unsigned long long)inc);
-      uint32_t t = (uint32_t)(old >> tagshift);
-      if (t == 0) {  // a free slot: claim it
-        uint64_t expect = old + inc;
-        for (;;) {
-          const uint64_t prev = atomicCAS(slot, (unsigned long long)expect, (unsigned long long)(expect | ((uint64_t)T << tagshift)));
-          if (prev == expect) { ++n_new; t = T; break; }
-          t = (uint32_t)(prev >> tagshift);
-          if (t) break;   // claimed meanwhile, perhaps for this very key
-          expect = prev;  // only counters moved
+      if (!pending && tail < seg_n && avail <= QW_RING - 64) {
+        pend = tail + lane < seg_n ? src[tail + lane] : QP_NONE;
+        pending = true;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const uint64_t need = __ballot(!live);
+      if (need == ~0ull && avail == 0 && !pending && head == seg_n) break;
+      if (need && avail) {
+        const uint32_t cnt = (uint32_t)__popcll((unsigned long long)need);
+        const uint32_t give = cnt < avail ? cnt : avail;
+        const uint32_t rank = lanes_below(need);
+        if (!live && rank < give) {
+          uint32_t at = head_mod + rank;
+          if (at >= QW_RING) at -= QW_RING;
+          const uint64_t e = __hip_atomic_load(&myring[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          T = (uint32_t)(e >> 32);
+          pos = (uint32_t)e & wmask;
+          q = ((uint32_t)e >> 16) & 1u;
+          left = (uint32_t)g.max_reprobe;
+          live = true;
         }
+        head += give;
+        head_mod += give;
+        if (head_mod >= QW_RING) head_mod -= QW_RING;
       }
-      if (t == T) {
-        live = false;  // counted
-      } else {
-        atomicAdd(slot, (unsigned long long)(0 - inc));  // another key lives here: withdraw, probe on
-        if (left == 0) {  // reprobe limit: leave it to the direct path
-          const uint32_t probe = (T & ((1u << g.pbits) - 1)) - 1;
-          const uint64_t home = ((uint64_t)w << QH_WINDOW_BITS) | ((pos - probe) & wmask);
-          const uint64_t h = (gsize >= 64 ? 0 : ((uint64_t)(T >> g.pbits) << gsize)) | (home << g.shard_bits) |
-                             (uint64_t)g.shard_id;
-          const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(&meta->spill_count), 1ull);
-          if (at < spill_cap) spill[at] = (h << 1) | q;
-          else meta->ovf_lost = 1;
-          live = false;
+      if (live) {
+        unsigned long long* slot = reinterpret_cast<unsigned long long*>(&win[pos]);
+        const uint64_t inc = q ? hinc : 1ull;
+        const uint64_t old = atomicAdd(slot, (unsigned long long)inc);
+        uint32_t t = (uint32_t)(old >> tagshift);
+        if (t == 0) {  // a free slot: claim it
+          uint64_t expect = old + inc;
+          for (;;) {
+            const uint64_t prev = atomicCAS(slot, (unsigned long long)expect, (unsigned long long)(expect | ((uint64_t)T << tagshift)));
+            if (prev == expect) { ++n_new; t = T; break; }
+            t = (uint32_t)(prev >> tagshift);
+            if (t) break;   // claimed meanwhile, perhaps for this very key
+            expect = prev;  // only counters moved
+          }
+        }
+        if (t == T) {
+          live = false;  // counted
         } else {
-          --left;
-          pos = (pos + 1) & wmask;
-          ++T;
+          atomicAdd(slot, (unsigned long long)(0 - inc));  // another key lives here: withdraw, probe on
+          if (left == 0) {  // reprobe limit: leave it to the direct path
+            const uint32_t probe = (T & ((1u << g.pbits) - 1)) - 1;
+            const uint64_t home = ((uint64_t)w << QH_WINDOW_BITS) | ((pos - probe) & wmask);
+            const uint64_t h = (gsize >= 64 ? 0 : ((uint64_t)(T >> g.pbits) << gsize)) | (home << g.shard_bits) |
+                               (uint64_t)g.shard_id;
+            const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(&meta->spill_count), 1ull);
+            if (at < spill_cap) spill[at] = (h << 1) | q;
+            else meta->ovf_lost = 1;
+            live = false;
+          } else {
+            --left;
+            pos = (pos + 1) & wmask;
+            ++T;
+          }
         }
       }
+    }
+    __syncthreads();  // every chain of the window has ended
+    n = n_next;
+    open_bucket(w + gridDim.x, n);  // the next bucket's first items travel while this window is written out
+#pragma unroll
+    for (uint32_t i = 0; i < nvec / QP_THREADS; ++i) {
+      const uint4 x = lw[i * QP_THREADS + tid];
+      const uint64_t a = to_table(((uint64_t)x.y << 32) | x.x), b = to_table(((uint64_t)x.w << 32) | x.z);
+      tw[i * QP_THREADS + tid] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
     }
   }
   n_new = wave_sum_u32(n_new);
   if (lane == 0) wnew[wave] = n_new;
   __syncthreads();
-#pragma unroll
-  for (uint32_t i = 0; i < nvec / QP_THREADS; ++i) {
-    const uint4 x = lw[i * QP_THREADS + tid];
-    const uint64_t a = to_table(((uint64_t)x.y << 32) | x.x), b = to_table(((uint64_t)x.w << 32) | x.z);
-    tw[i * QP_THREADS + tid] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
-  }
   if (tid == 0) {
     uint32_t t = 0;
     for (int i = 0; i < QP_WAVES; ++i) t += wnew[i];
@@ -801,8 +824,12 @@ void qh_launch_window_build(uint64_t* table, const qh_geom& g, const uint64_t* i
   if (cb > 31) cb = 31;
   const bool fits = tagbits <= 32 && cb >= 16 && (1ull << cb) > cap + g.max_val + 1;
   if (fits && !(force && !strcmp(force, "cas"))) {
-    hipLaunchKernelGGL(k_window_count, dim3(n_windows), dim3(QP_THREADS), 0, s, table, g, items, cap, counts, table_dirty,
-                       spill, spill_cap, meta, cb);
+    // one workgroup per CU walks the windows (see the kernel): QH_WINDOW_GRID overrides the grid for A/B tests
+    const char* gs = getenv("QH_WINDOW_GRID");
+    uint32_t grid = gs ? (uint32_t)atoi(gs) : 256u;
+    if (grid == 0 || grid > n_windows) grid = n_windows;
+    hipLaunchKernelGGL(k_window_count, dim3(grid), dim3(QP_THREADS), 0, s, table, g, items, cap, counts, n_windows,
+                       table_dirty, spill, spill_cap, meta, cb);
     return;
   }
   if (g.vbits + g.pbits <= 32)
