@@ -634,20 +634,30 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
 // by the launcher). The words are converted from / to the table's [tag | count << 1 | hq] form
 // when the window is loaded / stored. Used when tag bits + 2 * cb fit 64 with cb >= 16; other
 // geometries take k_window_build.
+//
+// CB16: cb == 16, i.e. the tag is the high word and both counters lie in the low word (no counter carry ever
+// crosses bit 32: H cannot overflow). Tag tests, claims and the chain state are then 32-bit operations. The
+// kernel is bound by the instructions a wave issues per round (one workgroup of 16 waves per CU, LDS, VALU
+// and HBM each about half used), so the round is kept short: a 128-entry ring whose refill and next request
+// are one step, liveness folded into the probe counter, the increment decoded once per item.
+#define QC_RING 128  // k_window_count: items per wave ring (power of two; at most 63 + 64 are queued)
+template <bool CB16>
 __global__ __launch_bounds__(QP_THREADS) void k_window_count(uint64_t* __restrict__ table, const qh_geom g,
                                                              const uint64_t* __restrict__ items, uint64_t cap,
                                                              const unsigned long long* __restrict__ counts,
                                                              uint32_t n_windows, int table_dirty,
                                                              uint64_t* __restrict__ spill, uint64_t spill_cap,
-                                                             qh_meta* __restrict__ meta, int cb) {
+                                                             qh_meta* __restrict__ meta, int cb_arg) {
   __shared__ uint64_t win[1u << QH_WINDOW_BITS];
-  __shared__ uint64_t ring[QP_WAVES][QW_RING];
+  __shared__ uint64_t ring[QP_WAVES][QC_RING];
   __shared__ uint32_t wnew[QP_WAVES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+  const int cb = CB16 ? 16 : cb_arg;
   const int tagshift = 2 * cb;  // >= 32
-  const uint64_t cmask = (1ull << cb) - 1, hinc = 1ull << cb;
+  const uint64_t cmask = (1ull << cb) - 1;
+  const uint32_t hinc = 1u << cb;  // cb <= 31
   uint4* lw = reinterpret_cast<uint4*>(win);
   const uint32_t nvec = (1u << QH_WINDOW_BITS) / 2;  // 16-byte pieces
   auto to_counting = [&](uint64_t slot) -> uint64_t {
@@ -670,7 +680,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_count(uint64_t* __restric
   // window is counted, the first items of this wave's segment of it before this window is written out.
   uint32_t seg_n = 0;             // this wave's segment of the bucket: src[0 .. seg_n)
   const uint64_t* src = items;
-  uint64_t pend = QP_NONE;        // its first 64 items, requested
+  uint64_t pend = QP_NONE;        // items [tail, tail + 64) of the segment, requested whenever tail < seg_n
   auto open_bucket = [&](uint32_t w, uint64_t n) {
     const uint32_t seg = (uint32_t)((n + QP_WAVES - 1) / QP_WAVES);
     const uint32_t s0 = (uint32_t)(((uint64_t)wave * seg) < n ? (uint64_t)wave * seg : n);
@@ -711,86 +721,71 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_count(uint64_t* __restric
     }
     __syncthreads();
 
-    uint32_t head = 0, tail = 0, head_mod = 0, tail_mod = 0;  // wave-uniform ring state (see k_window_build)
-    bool pending = seg_n > 0;
-    bool live = false;
-    uint32_t T = 0, pos = 0, left = 0, q = 0;  // chain state: tag at this probe, position, probes left, quality
+    uint32_t head = 0, tail = 0;  // wave-uniform ring state: items dealt, items queued (positions modulo QC_RING)
+    // chain state: tag at this probe, position, increment (1, or 1 << cb with quality), probes left (< 0: no chain)
+    uint32_t T = 0, pos = 0, inc = 1;
+    int left = -1;
 
     for (;;) {
       uint32_t avail = tail - head;
-      if (pending && avail < 64) {
+      if (avail < 64 && tail < seg_n) {
         // decoded once, with every lane busy: {position | q << 16, tag at probe 0}
         const uint64_t h = pend >> 1;
         const uint32_t p0 = (uint32_t)(h >> g.shard_bits) & wmask;
         const uint32_t t0 = ((uint32_t)(gsize >= 64 ? 0 : (h >> gsize)) << g.pbits) | 1u;
-        uint32_t at = tail_mod + lane;
-        if (at >= QW_RING) at -= QW_RING;
-        myring[at] = ((uint64_t)t0 << 32) | p0 | (((uint32_t)pend & 1u) << 16);
-        const uint32_t got = seg_n - tail < 64 ? seg_n - tail : 64;
-        tail += got;
-        tail_mod += got;
-        if (tail_mod >= QW_RING) tail_mod -= QW_RING;
-        pending = false;
-        avail = tail - head;
-      }
-      if (!pending && tail < seg_n && avail <= QW_RING - 64) {
-        pend = tail + lane < seg_n ? src[tail + lane] : QP_NONE;
-        pending = true;
+        myring[(tail + lane) & (QC_RING - 1)] = ((uint64_t)t0 << 32) | p0 | (((uint32_t)pend & 1u) << 16);
+        tail += seg_n - tail < 64 ? seg_n - tail : 64;
+        if (tail < seg_n) pend = tail + lane < seg_n ? src[tail + lane] : QP_NONE;
+        avail = tail - head;  // >= 64 unless the segment has ended
       }
       __builtin_amdgcn_wave_barrier();
-      const uint64_t need = __ballot(!live);
-      if (need == ~0ull && avail == 0 && !pending && head == seg_n) break;
-      if (need && avail) {
+      const uint64_t need = __ballot(left < 0);
+      if (need == ~0ull && avail == 0) break;  // nothing queued means nothing left to queue
+      {
         const uint32_t cnt = (uint32_t)__popcll((unsigned long long)need);
         const uint32_t give = cnt < avail ? cnt : avail;
         const uint32_t rank = lanes_below(need);
-        if (!live && rank < give) {
-          uint32_t at = head_mod + rank;
-          if (at >= QW_RING) at -= QW_RING;
-          const uint64_t e = __hip_atomic_load(&myring[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (left < 0 && rank < give) {
+          const uint64_t e = __hip_atomic_load(&myring[(head + rank) & (QC_RING - 1)], __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
           T = (uint32_t)(e >> 32);
           pos = (uint32_t)e & wmask;
-          q = ((uint32_t)e >> 16) & 1u;
-          left = (uint32_t)g.max_reprobe;
-          live = true;
+          inc = ((uint32_t)e >> 16) & 1u ? hinc : 1u;
+          left = (int)g.max_reprobe;
         }
         head += give;
-        head_mod += give;
-        if (head_mod >= QW_RING) head_mod -= QW_RING;
       }
-      if (live) {
+      if (left >= 0) {
         unsigned long long* slot = reinterpret_cast<unsigned long long*>(&win[pos]);
-        const uint64_t inc = q ? hinc : 1ull;
         const uint64_t old = atomicAdd(slot, (unsigned long long)inc);
-        uint32_t t = (uint32_t)(old >> tagshift);
+        uint32_t t = CB16 ? (uint32_t)(old >> 32) : (uint32_t)(old >> tagshift);
         if (t == 0) {  // a free slot: claim it
           uint64_t expect = old + inc;
           for (;;) {
-            const uint64_t prev = atomicCAS(slot, (unsigned long long)expect, (unsigned long long)(expect | ((uint64_t)T << tagshift)));
+            const uint64_t mine = CB16 ? (((uint64_t)T << 32) | (uint32_t)expect) : (expect | ((uint64_t)T << tagshift));
+            const uint64_t prev = atomicCAS(slot, (unsigned long long)expect, (unsigned long long)mine);
             if (prev == expect) { ++n_new; t = T; break; }
-            t = (uint32_t)(prev >> tagshift);
+            t = CB16 ? (uint32_t)(prev >> 32) : (uint32_t)(prev >> tagshift);
             if (t) break;   // claimed meanwhile, perhaps for this very key
             expect = prev;  // only counters moved
           }
         }
         if (t == T) {
-          live = false;  // counted
+          left = -1;  // counted
         } else {
-          atomicAdd(slot, (unsigned long long)(0 - inc));  // another key lives here: withdraw, probe on
+          atomicAdd(slot, 0ull - (unsigned long long)inc);  // another key lives here: withdraw, probe on
           if (left == 0) {  // reprobe limit: leave it to the direct path
             const uint32_t probe = (T & ((1u << g.pbits) - 1)) - 1;
             const uint64_t home = ((uint64_t)w << QH_WINDOW_BITS) | ((pos - probe) & wmask);
             const uint64_t h = (gsize >= 64 ? 0 : ((uint64_t)(T >> g.pbits) << gsize)) | (home << g.shard_bits) |
                                (uint64_t)g.shard_id;
             const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(&meta->spill_count), 1ull);
-            if (at < spill_cap) spill[at] = (h << 1) | q;
+            if (at < spill_cap) spill[at] = (h << 1) | (inc != 1u ? 1u : 0u);
             else meta->ovf_lost = 1;
-            live = false;
-          } else {
-            --left;
-            pos = (pos + 1) & wmask;
-            ++T;
           }
+          --left;
+          pos = (pos + 1) & wmask;
+          ++T;
         }
       }
     }
@@ -818,7 +813,7 @@ void qh_launch_window_build(uint64_t* table, const qh_geom& g, const uint64_t* i
                             const unsigned long long* counts, uint32_t n_windows, int table_dirty, uint64_t* spill,
                             uint64_t spill_cap, qh_meta* meta, hipStream_t s) {
   // counting form when [tag | H | L] fits 64 bits with counters that can hold a whole bucket
-  const char* force = getenv("QH_WINDOW_KERNEL");  // "cas": the compare-and-swap kernels everywhere (A/B tests)
+  const char* force = getenv("QH_WINDOW_KERNEL");  // A/B tests: "cas" compare-and-swap kernels, "count" generic counters
   const int tagbits = g.rbits + g.pbits;
   int cb = (64 - tagbits) / 2;
   if (cb > 31) cb = 31;
@@ -828,8 +823,13 @@ void qh_launch_window_build(uint64_t* table, const qh_geom& g, const uint64_t* i
     const char* gs = getenv("QH_WINDOW_GRID");
     uint32_t grid = gs ? (uint32_t)atoi(gs) : 256u;
     if (grid == 0 || grid > n_windows) grid = n_windows;
-    hipLaunchKernelGGL(k_window_count, dim3(grid), dim3(QP_THREADS), 0, s, table, g, items, cap, counts, n_windows,
-                       table_dirty, spill, spill_cap, meta, cb);
+    const bool cb16 = 65536ull > cap + g.max_val + 1 && !(force && !strcmp(force, "count"));  // "count": generic form
+    if (cb16)
+      hipLaunchKernelGGL(k_window_count<true>, dim3(grid), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
+                         n_windows, table_dirty, spill, spill_cap, meta, 16);
+    else
+      hipLaunchKernelGGL(k_window_count<false>, dim3(grid), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
+                         n_windows, table_dirty, spill, spill_cap, meta, cb);
     return;
   }
   if (g.vbits + g.pbits <= 32)

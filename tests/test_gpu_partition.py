@@ -55,7 +55,7 @@ def test_window_kernels_agree(k, bits, size, monkeypatch):
     om, ov = db.sorted_dump()
     assert (ov >> np.uint64(1)).max() == (1 << bits) - 1  # saturation is reached
     assert 0 < (ov & np.uint64(1)).sum() < ov.size        # both quality levels present
-    for kernel in ("count", "cas"):
+    for kernel in ("count16", "count", "cas"):  # the default (16-bit counters where the bucket allows), generic counters, CAS
         monkeypatch.setenv("QH_WINDOW_KERNEL", kernel)
         h, st, m, v = build(data, k, bits, size, "partition", chunks=3)
         assert st["instances"] == n and st["distinct"] == om.size
