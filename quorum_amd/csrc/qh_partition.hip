@@ -657,7 +657,6 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_count(uint64_t* __restric
   const int cb = CB16 ? 16 : cb_arg;
   const int tagshift = 2 * cb;  // >= 32
   const uint64_t cmask = (1ull << cb) - 1;
-  const uint32_t hinc = 1u << cb;  // cb <= 31
   uint4* lw = reinterpret_cast<uint4*>(win);
   const uint32_t nvec = (1u << QH_WINDOW_BITS) / 2;  // 16-byte pieces
   auto to_counting = [&](uint64_t slot) -> uint64_t {
@@ -721,27 +720,32 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_count(uint64_t* __restric
     }
     __syncthreads();
 
-    uint32_t head = 0, tail = 0;  // wave-uniform ring state: items dealt, items queued (positions modulo QC_RING)
+    // wave-uniform ring state: items dealt, items queued (positions modulo QC_RING), and the queue length below
+    // which the next 64 are queued (0 once the segment has ended)
+    uint32_t head = 0, tail = 0, gate = seg_n ? 64 : 0;
     // chain state: tag at this probe, position, increment (1, or 1 << cb with quality), probes left (< 0: no chain)
     uint32_t T = 0, pos = 0, inc = 1;
     int left = -1;
 
     for (;;) {
       uint32_t avail = tail - head;
-      if (avail < 64 && tail < seg_n) {
-        // decoded once, with every lane busy: {position | q << 16, tag at probe 0}
+      if (avail < gate) {
+        // decoded once, with every lane busy: {position | log2(increment) << 16, tag at probe 0}
         const uint64_t h = pend >> 1;
         const uint32_t p0 = (uint32_t)(h >> g.shard_bits) & wmask;
         const uint32_t t0 = ((uint32_t)(gsize >= 64 ? 0 : (h >> gsize)) << g.pbits) | 1u;
-        myring[(tail + lane) & (QC_RING - 1)] = ((uint64_t)t0 << 32) | p0 | (((uint32_t)pend & 1u) << 16);
+        const uint32_t sh = (uint32_t)pend & 1u ? (uint32_t)cb : 0u;
+        myring[(tail + lane) & (QC_RING - 1)] = ((uint64_t)t0 << 32) | p0 | (sh << 16);
         tail += seg_n - tail < 64 ? seg_n - tail : 64;
         if (tail < seg_n) pend = tail + lane < seg_n ? src[tail + lane] : QP_NONE;
+        else gate = 0;
         avail = tail - head;  // >= 64 unless the segment has ended
       }
       __builtin_amdgcn_wave_barrier();
       const uint64_t need = __ballot(left < 0);
-      if (need == ~0ull && avail == 0) break;  // nothing queued means nothing left to queue
-      {
+      if (avail == 0) {  // nothing queued means nothing left to queue
+        if (need == ~0ull) break;
+      } else {
         const uint32_t cnt = (uint32_t)__popcll((unsigned long long)need);
         const uint32_t give = cnt < avail ? cnt : avail;
         const uint32_t rank = lanes_below(need);
@@ -750,7 +754,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_count(uint64_t* __restric
                                                __HIP_MEMORY_SCOPE_WORKGROUP);
           T = (uint32_t)(e >> 32);
           pos = (uint32_t)e & wmask;
-          inc = ((uint32_t)e >> 16) & 1u ? hinc : 1u;
+          inc = 1u << (((uint32_t)e >> 16) & 31u);
           left = (int)g.max_reprobe;
         }
         head += give;
@@ -759,33 +763,49 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_count(uint64_t* __restric
         unsigned long long* slot = reinterpret_cast<unsigned long long*>(&win[pos]);
         const uint64_t old = atomicAdd(slot, (unsigned long long)inc);
         uint32_t t = CB16 ? (uint32_t)(old >> 32) : (uint32_t)(old >> tagshift);
-        if (t == 0) {  // a free slot: claim it
+        if (t == 0) {  // a free slot: claim it, sighting included
+          // Tried again in place while only counters move: every failure is then another chain's add or
+          // withdrawal, of which there are finitely many. (Withdrawing and coming back in the next round
+          // instead lets two waves in step fail each other's compare-and-swap for seconds.)
           uint64_t expect = old + inc;
-          for (;;) {
-            const uint64_t mine = CB16 ? (((uint64_t)T << 32) | (uint32_t)expect) : (expect | ((uint64_t)T << tagshift));
-            const uint64_t prev = atomicCAS(slot, (unsigned long long)expect, (unsigned long long)mine);
-            if (prev == expect) { ++n_new; t = T; break; }
-            t = CB16 ? (uint32_t)(prev >> 32) : (uint32_t)(prev >> tagshift);
-            if (t) break;   // claimed meanwhile, perhaps for this very key
-            expect = prev;  // only counters moved
+          auto mine = [&](uint64_t e) -> uint64_t {
+            return CB16 ? (((uint64_t)T << 32) | (uint32_t)e) : (e | ((uint64_t)T << tagshift));
+          };
+          uint64_t prev = atomicCAS(slot, (unsigned long long)expect, (unsigned long long)mine(expect));
+          bool claimed = prev == expect;
+          t = CB16 ? (uint32_t)(prev >> 32) : (uint32_t)(prev >> tagshift);
+          if (__builtin_expect(!claimed && t == 0, 0)) {
+            do {
+              expect = prev;
+              prev = atomicCAS(slot, (unsigned long long)expect, (unsigned long long)mine(expect));
+              claimed = prev == expect;
+              t = CB16 ? (uint32_t)(prev >> 32) : (uint32_t)(prev >> tagshift);
+            } while (!claimed && t == 0);
+          }
+          if (claimed) {
+            ++n_new;
+            t = T;
           }
         }
         if (t == T) {
           left = -1;  // counted
         } else {
-          atomicAdd(slot, 0ull - (unsigned long long)inc);  // another key lives here: withdraw, probe on
-          if (left == 0) {  // reprobe limit: leave it to the direct path
-            const uint32_t probe = (T & ((1u << g.pbits) - 1)) - 1;
-            const uint64_t home = ((uint64_t)w << QH_WINDOW_BITS) | ((pos - probe) & wmask);
-            const uint64_t h = (gsize >= 64 ? 0 : ((uint64_t)(T >> g.pbits) << gsize)) | (home << g.shard_bits) |
-                               (uint64_t)g.shard_id;
-            const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(&meta->spill_count), 1ull);
-            if (at < spill_cap) spill[at] = (h << 1) | (inc != 1u ? 1u : 0u);
-            else meta->ovf_lost = 1;
+          // another key lives here: withdraw and probe on
+          __hip_atomic_fetch_sub(slot, (unsigned long long)inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          {
+            if (left == 0) {  // reprobe limit: leave it to the direct path
+              const uint32_t probe = (T & ((1u << g.pbits) - 1)) - 1;
+              const uint64_t home = ((uint64_t)w << QH_WINDOW_BITS) | ((pos - probe) & wmask);
+              const uint64_t h = (gsize >= 64 ? 0 : ((uint64_t)(T >> g.pbits) << gsize)) | (home << g.shard_bits) |
+                                 (uint64_t)g.shard_id;
+              const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(&meta->spill_count), 1ull);
+              if (at < spill_cap) spill[at] = (h << 1) | (inc != 1u ? 1u : 0u);
+              else meta->ovf_lost = 1;
+            }
+            --left;
+            pos = (pos + 1) & wmask;
+            ++T;
           }
-          --left;
-          pos = (pos + 1) & wmask;
-          ++T;
         }
       }
     }
