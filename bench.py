@@ -141,7 +141,8 @@ def main():
         # names as rocprofv3 prints them: k_partition<0> = FASTQ source (level 1), k_partition<1> = item source
         knames = ("segments(k_rec_segs_sum+k_scan_u32+k_rec_segs_apply)" if partitioned and world == 1
                   else "k_build_direct" if world == 1 else "k_insert_items", "k_partition<0>" if world == 1 else "k_partition<1> (level 1)",
-                  "k_partition<1>" if world == 1 else "k_partition<1> (level 2)", "k_window_count")  # the counting form at this geometry
+                  "k_partition<1>" if world == 1 else "k_partition<1> (level 2)",
+                  "k_window_count<true>")  # the counting form with 16-bit counters at this geometry
         per_launch = st["instances"]                # this rank's insertions per launch of the dominant kernel
         achieved = per_launch * ALG_BYTES_PER_KMER / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
         traffic = None
