@@ -428,10 +428,11 @@ void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsign
 // read ("claim" rounds expect 0 and offer a fresh entry; "update" rounds expect the word the
 // previous round returned). Probe lengths differ wildly between lanes, so a lane whose chain
 // ends is handed the wave's next item at once: each wave owns a contiguous segment of the
-// bucket, streams it 64 items at a time through a private LDS ring (one coalesced global load
-// in flight ahead of use), and deals items to idle lanes by ballot rank. Nearly every CAS
+// bucket, streams it 64 items at a time through a private LDS ring (queued when fewer than 64 are
+// left in it, the next coalesced global load requested in the same step), and deals items to idle
+// lanes by ballot rank. Nearly every CAS
 // wave-instruction therefore carries 64 live lanes.
-#define QW_RING 192  // items per wave ring (1.5 KiB)
+#define QW_RING 128  // items per wave ring (1 KiB, a power of two): at most 63 queued + 64 arriving
 
 // NARROW: value and probe fields lie in the low 32 bits of the slot (vbits + pbits <= 32, true
 // for every -b up to 24 at -p 126). Probing then only ever changes the low half of the word a
@@ -464,9 +465,9 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
   const uint32_t s0 = (uint32_t)(((uint64_t)wave * seg) < n ? (uint64_t)wave * seg : n);
   const uint32_t seg_n = (uint32_t)((uint64_t)s0 + seg <= n ? seg : n - s0);
   const uint64_t* src = items + (uint64_t)w * cap + s0;
-  // first 64 items in flight while the window is brought into LDS
+  // first 64 items in flight while the window is brought into LDS; items [tail, tail + 64) are on request
+  // whenever tail < seg_n
   uint64_t pend = (uint32_t)lane < seg_n ? src[lane] : QP_NONE;
-  bool pending = seg_n > 0;
   uint4* tw = reinterpret_cast<uint4*>(table + ((uint64_t)w << QH_WINDOW_BITS));
   uint4* lw = reinterpret_cast<uint4*>(win);
   const uint32_t nvec = (1u << QH_WINDOW_BITS) / 2;  // 16-byte pieces
@@ -485,8 +486,9 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
   const uint32_t vkeep_lo = (uint32_t)vkeep, vmask_lo = (uint32_t)g.vmask, one_probe_lo = (uint32_t)one_probe;
   const uint32_t maxv_lo = (uint32_t)g.max_val;
   uint64_t* myring = ring[wave];
-  uint32_t head = 0, tail = 0;          // items dealt / items in the ring so far (wave-uniform)
-  uint32_t head_mod = 0, tail_mod = 0;  // the same modulo QW_RING
+  // wave-uniform ring state: items dealt, items queued (positions modulo QW_RING), and the queue length below
+  // which the next 64 are queued (0 once the segment has ended)
+  uint32_t head = 0, tail = 0, gate = seg_n ? 64 : 0;
   uint32_t n_new = 0;
   // chain state
   bool live = false;
@@ -496,35 +498,24 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
 
   for (;;) {
     uint32_t avail = tail - head;
-    // commit the load in flight once the ring runs low
-    if (pending && avail < 64) {
-      uint32_t at = tail_mod + lane;
-      if (at >= QW_RING) at -= QW_RING;
-      myring[at] = pend;
-      const uint32_t got = seg_n - tail < 64 ? seg_n - tail : 64;
-      tail += got;
-      tail_mod += got;
-      if (tail_mod >= QW_RING) tail_mod -= QW_RING;
-      pending = false;
-      avail = tail - head;
-    }
-    // keep one 64-item load in flight ahead of use
-    if (!pending && tail < seg_n && avail <= QW_RING - 64) {
-      pend = tail + lane < seg_n ? src[tail + lane] : QP_NONE;
-      pending = true;
+    if (avail < gate) {  // the ring runs low: queue the items that have arrived, request the next
+      myring[(tail + lane) & (QW_RING - 1)] = pend;
+      tail += seg_n - tail < 64 ? seg_n - tail : 64;
+      if (tail < seg_n) pend = tail + lane < seg_n ? src[tail + lane] : QP_NONE;
+      else gate = 0;
+      avail = tail - head;  // >= 64 unless the segment has ended
     }
     __builtin_amdgcn_wave_barrier();
     // deal items to idle lanes
     const uint64_t need = __ballot(!live);
-    if (need == ~0ull && avail == 0 && !pending && head == seg_n) break;  // all idle, nothing left to deal
-    if (need && avail) {
+    if (avail == 0) {  // nothing queued means nothing left to queue
+      if (need == ~0ull) break;
+    } else {
       const uint32_t cnt = (uint32_t)__popcll((unsigned long long)need);
       const uint32_t give = cnt < avail ? cnt : avail;
       const uint32_t rank = lanes_below(need);
       if (!live && rank < give) {
-        uint32_t at = head_mod + rank;
-        if (at >= QW_RING) at -= QW_RING;
-        v = __hip_atomic_load(&myring[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        v = __hip_atomic_load(&myring[(head + rank) & (QW_RING - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const uint64_t h = v >> 1;
         pos = (uint32_t)(h >> g.shard_bits) & wmask;
         // want = (remainder | probe+1) << vbits: our key's slot word at this probe with a zero value
@@ -543,8 +534,6 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
         live = true;
       }
       head += give;
-      head_mod += give;
-      if (head_mod >= QW_RING) head_mod -= QW_RING;
     }
     // one round: a single compare-and-swap per live lane
     if (live) {
@@ -640,7 +629,6 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
 // kernel is bound by the instructions a wave issues per round (one workgroup of 16 waves per CU, LDS, VALU
 // and HBM each about half used), so the round is kept short: a 128-entry ring whose refill and next request
 // are one step, liveness folded into the probe counter, the increment decoded once per item.
-#define QC_RING 128  // k_window_count: items per wave ring (power of two; at most 63 + 64 are queued)
 template <bool CB16>
 __global__ __launch_bounds__(QP_THREADS) void k_window_count(uint64_t* __restrict__ table, const qh_geom g,
                                                              const uint64_t* __restrict__ items, uint64_t cap,
@@ -649,7 +637,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_count(uint64_t* __restric
                                                              uint64_t* __restrict__ spill, uint64_t spill_cap,
                                                              qh_meta* __restrict__ meta, int cb_arg) {
   __shared__ uint64_t win[1u << QH_WINDOW_BITS];
-  __shared__ uint64_t ring[QP_WAVES][QC_RING];
+  __shared__ uint64_t ring[QP_WAVES][QW_RING];
   __shared__ uint32_t wnew[QP_WAVES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -720,7 +708,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_count(uint64_t* __restric
     }
     __syncthreads();
 
-    // wave-uniform ring state: items dealt, items queued (positions modulo QC_RING), and the queue length below
+    // wave-uniform ring state: items dealt, items queued (positions modulo QW_RING), and the queue length below
     // which the next 64 are queued (0 once the segment has ended)
     uint32_t head = 0, tail = 0, gate = seg_n ? 64 : 0;
     // chain state: tag at this probe, position, increment (1, or 1 << cb with quality), probes left (< 0: no chain)
@@ -735,7 +723,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_count(uint64_t* __restric
         const uint32_t p0 = (uint32_t)(h >> g.shard_bits) & wmask;
         const uint32_t t0 = ((uint32_t)(gsize >= 64 ? 0 : (h >> gsize)) << g.pbits) | 1u;
         const uint32_t sh = (uint32_t)pend & 1u ? (uint32_t)cb : 0u;
-        myring[(tail + lane) & (QC_RING - 1)] = ((uint64_t)t0 << 32) | p0 | (sh << 16);
+        myring[(tail + lane) & (QW_RING - 1)] = ((uint64_t)t0 << 32) | p0 | (sh << 16);
         tail += seg_n - tail < 64 ? seg_n - tail : 64;
         if (tail < seg_n) pend = tail + lane < seg_n ? src[tail + lane] : QP_NONE;
         else gate = 0;
@@ -750,7 +738,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_count(uint64_t* __restric
         const uint32_t give = cnt < avail ? cnt : avail;
         const uint32_t rank = lanes_below(need);
         if (left < 0 && rank < give) {
-          const uint64_t e = __hip_atomic_load(&myring[(head + rank) & (QC_RING - 1)], __ATOMIC_RELAXED,
+          const uint64_t e = __hip_atomic_load(&myring[(head + rank) & (QW_RING - 1)], __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_WORKGROUP);
           T = (uint32_t)(e >> 32);
           pos = (uint32_t)e & wmask;
