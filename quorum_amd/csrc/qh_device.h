@@ -210,12 +210,14 @@ __device__ __forceinline__ void qh_canonical_planes(uint32_t m0, uint32_t m1, ui
 // planes: m = forward, r = reverse complement. Same value as qh_mix_pair(canonical, other), with the
 // two comparisons -- whole mers for the key (create_database.cc:86), cores for the home slot -- sharing
 // their XORs and made in place (the core is bits 1..k-2 of the planes).
-__device__ __forceinline__ uint64_t qh_hash_strands(uint32_t m0, uint32_t m1, uint32_t r0, uint32_t r1, int k) {
+// SMALLK: k < 4 (no core: the whole key is hashed); callers in a per-item loop pick the form once
+template <bool SMALLK>
+__device__ __forceinline__ uint64_t qh_hash_strands_form(uint32_t m0, uint32_t m1, uint32_t r0, uint32_t r1, int k) {
   const uint32_t x0 = m0 ^ r0, x1 = m1 ^ r1, xa = x0 | x1;
   const int cf = __clz((int)xa) & 31;  // xa == 0 (palindrome): either strand
   const bool fwd = (int32_t)((((int32_t)(x1 << cf) < 0) ? m1 : m0) << cf) >= 0;
   const uint32_t c0 = fwd ? m0 : r0, c1 = fwd ? m1 : r1;
-  if (k < 4) return qh_feistel3(c0, c1, k);
+  if (SMALLK) return qh_feistel3(c0, c1, k);
   const int kc = k - 2;
   const uint32_t cm = (1u << kc) - 1u;
   const uint32_t xc = xa & (cm << 1), xc1 = x1 & (cm << 1);
@@ -225,6 +227,10 @@ __device__ __forceinline__ uint64_t qh_hash_strands(uint32_t m0, uint32_t m1, ui
   const uint32_t cL = ((cfwd ? m0 : r0) >> 1) & cm, cR = ((cfwd ? m1 : r1) >> 1) & cm;
   const uint32_t e = (c0 & 1u) | ((c1 & 1u) << 1) | ((c0 >> (k - 1)) << 2) | ((c1 >> (k - 1)) << 3);
   return (qh_feistel3(cL, cR, kc) ^ QH_MIX_Z) | ((uint64_t)(e | ((uint32_t)(fwd != cfwd) << 4)) << (2 * kc));
+}
+
+__device__ __forceinline__ uint64_t qh_hash_strands(uint32_t m0, uint32_t m1, uint32_t r0, uint32_t r1, int k) {
+  return k < 4 ? qh_hash_strands_form<true>(m0, m1, r0, r1, k) : qh_hash_strands_form<false>(m0, m1, r0, r1, k);
 }
 
 __device__ __forceinline__ uint64_t qh_canonical_pkey(uint32_t m0, uint32_t m1, uint32_t r0, uint32_t r1, int k) {

@@ -176,7 +176,9 @@ __device__ __forceinline__ void qp_spill(const qp_params& p, uint64_t item) {
   else p.meta->ovf_lost = 1;
 }
 
-template <int SRC>
+// OWNER: items are checked against the shard that owns them (p.check_owner); SMALLK: k < 4. Both are the same for
+// every item of a launch, and the extraction loop is bound by the instructions it issues per k-mer.
+template <int SRC, bool OWNER, bool SMALLK>
 __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, const qh_geom g) {
   __shared__ uint64_t sorted[QP_TILE_ITEMS];
   __shared__ uint32_t cursor[QP_MAX_BINS];  // histogram, then running placement cursor
@@ -275,8 +277,8 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
             const uint32_t q = ((uint32_t)(wh >> j) & kones) == kones;         // high_len >= k (:86)
             const uint32_t r0 = ~(uint32_t)(w0 >> j) & kones, r1 = ~(uint32_t)(w1 >> j) & kones;
             const uint32_t m0 = (uint32_t)(f0 >> (QP_SEG - 1 - j)) & kones, m1 = (uint32_t)(f1 >> (QP_SEG - 1 - j)) & kones;
-            const uint64_t h = qh_hash_strands(m0, m1, r0, r1, g.k);  // min(m, rm) of create_database.cc:86, hashed
-            if (p.check_owner && ((uint32_t)h & smask) != (uint32_t)g.shard_id) {
+            const uint64_t h = qh_hash_strands_form<SMALLK>(m0, m1, r0, r1, g.k);  // min(m, rm) of create_database.cc:86, hashed
+            if (OWNER && ((uint32_t)h & smask) != (uint32_t)g.shard_id) {
               ++n_foreign;
             } else {
               ++n_inst; n_hq += q;
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
         if (raw[i] != QP_NONE) {
           const uint32_t q = (uint32_t)(raw[i] & 1);
           const uint64_t h = p.in_hashed ? ((raw[i] >> 1) & g.hmask) : qh_hash_key((raw[i] >> 1) & g.kmask, g.k);
-          if (p.check_owner && ((uint32_t)h & smask) != (uint32_t)g.shard_id) {
+          if (OWNER && ((uint32_t)h & smask) != (uint32_t)g.shard_id) {
             ++n_foreign;
           } else {
             ++n_inst; n_hq += q;
@@ -401,7 +403,14 @@ void qh_launch_partition_fastq(const qh_fastq_aux& a, uint32_t rec_cap, qh_meta*
   fill_common(p, d, meta, check_owner, 1);
   p.planes = a.planes; p.plane_words = a.plane_words; p.seg_desc = a.seg_desc;
   p.seg_total = a.tile_sums + (rec_cap + RB_TILE - 1) / RB_TILE;
-  hipLaunchKernelGGL(k_partition<QP_SRC_FASTQ>, dim3(256), dim3(QP_THREADS), 0, s, p, g);
+  const dim3 grid(256), block(QP_THREADS);
+  if (g.k < 4) {
+    if (check_owner) hipLaunchKernelGGL((k_partition<QP_SRC_FASTQ, true, true>), grid, block, 0, s, p, g);
+    else hipLaunchKernelGGL((k_partition<QP_SRC_FASTQ, false, true>), grid, block, 0, s, p, g);
+  } else {
+    if (check_owner) hipLaunchKernelGGL((k_partition<QP_SRC_FASTQ, true, false>), grid, block, 0, s, p, g);
+    else hipLaunchKernelGGL((k_partition<QP_SRC_FASTQ, false, false>), grid, block, 0, s, p, g);
+  }
 }
 
 void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsigned long long* in_counts,
@@ -416,7 +425,9 @@ void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsign
   // one workgroup per CU is resident (144 KiB of LDS): grid-stride the tiles of a bucket
   uint64_t gx = n_in_buckets >= 256 ? 1 : (256 + n_in_buckets - 1) / n_in_buckets * 2;
   if (gx > tiles) gx = tiles;
-  hipLaunchKernelGGL(k_partition<QP_SRC_ITEMS>, dim3((unsigned)gx, n_in_buckets), dim3(QP_THREADS), 0, s, p, g);
+  const dim3 grid((unsigned)gx, n_in_buckets), block(QP_THREADS);
+  if (check_owner) hipLaunchKernelGGL((k_partition<QP_SRC_ITEMS, true, false>), grid, block, 0, s, p, g);
+  else hipLaunchKernelGGL((k_partition<QP_SRC_ITEMS, false, false>), grid, block, 0, s, p, g);
 }
 
 // ----------------------------------------------------------------- window build
