@@ -373,7 +373,13 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
       const uint64_t v = sorted[j];
       const uint32_t b = (uint32_t)((v >> 1) >> p.bin_shift) & p.bin_mask;
       const uint64_t dst = (uint64_t)gbase[b] + (j - offs[b]);
-      if (dst < p.out_cap) p.out[(((uint64_t)in_bucket << p.out_bin_shift) | b) * p.out_cap + dst] = v;
+      if (dst < p.out_cap) {
+        uint64_t* at = &p.out[(((uint64_t)in_bucket << p.out_bin_shift) | b) * p.out_cap + dst];
+        // level 1's buckets are read once, by level 2, after all of them are written: kept out of the caches
+        // (level 2 then runs 5 % faster; the same hint on level 2's own stores or on the item loads costs time)
+        if (SRC == QP_SRC_FASTQ) __builtin_nontemporal_store(v, at);
+        else *at = v;
+      }
       else qp_spill(p, v);
     }
     __syncthreads();
