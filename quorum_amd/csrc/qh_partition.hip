@@ -821,7 +821,9 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_count(uint64_t* __restric
     for (uint32_t i = 0; i < nvec / QP_THREADS; ++i) {
       const uint4 x = lw[i * QP_THREADS + tid];
       const uint64_t a = to_table(((uint64_t)x.y << 32) | x.x), b = to_table(((uint64_t)x.w << 32) | x.z);
-      tw[i * QP_THREADS + tid] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+      typedef uint32_t qh_v4u __attribute__((ext_vector_type(4)));
+      const qh_v4u o = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+      __builtin_nontemporal_store(o, reinterpret_cast<qh_v4u*>(tw + i * QP_THREADS + tid));
     }
   }
   n_new = wave_sum_u32(n_new);
