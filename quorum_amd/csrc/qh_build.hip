@@ -332,7 +332,7 @@ static int fastq_aux(qh_build* h, size_t buf_len, size_t rec_cap, size_t max_bas
   const size_t segs = max_bases / QH_SEG_KMERS + rec_cap, plane_words = (buf_len + 63) / 64 + 2;
   int rc;
   if ((rc = ensure((void**)&h->d_rbsums, &h->rbsums_cap, (rec_cap / 1024 + 4) * 4, "segment sums"))) return rc;
-  if ((rc = ensure((void**)&h->d_segdesc, &h->segdesc_cap, (segs + 2) * 16, "segment descriptors"))) return rc;
+  if ((rc = ensure((void**)&h->d_segdesc, &h->segdesc_cap, (segs + 2) * 8, "segment descriptors"))) return rc;
   if ((rc = ensure((void**)&h->d_planes, &h->planes_cap, plane_words * 32, "bit planes"))) return rc;
   *a = {h->d_rbsums, h->d_segdesc, h->d_planes, plane_words};
   return QH_OK;

@@ -23,7 +23,7 @@ struct qh_build {
   uint64_t* d_shard_counts = nullptr;
   // radix-partitioned build: block prefix of the record table, bucket levels
   uint32_t* d_rbsums = nullptr;    size_t rbsums_cap = 0;
-  uint4* d_segdesc = nullptr;      size_t segdesc_cap = 0;  // per-segment descriptors
+  uint2* d_segdesc = nullptr;      size_t segdesc_cap = 0;  // per-segment descriptors
   uint64_t* d_planes = nullptr;    size_t planes_cap = 0;   // bit planes of the chunk
   uint64_t* d_bins[2] = {nullptr, nullptr}; size_t bins_cap[2] = {0, 0};       // level-1 / window buckets (bytes)
   unsigned long long* d_bin_counts[2] = {nullptr, nullptr}; size_t bin_counts_cap[2] = {0, 0};

@@ -71,13 +71,13 @@ struct qh_part_dst {
 #define QH_COUNT_STRIDE 513u
 // Per-chunk device arrays of the FASTQ source (qh_partition.hip):
 //   tile_sums  ceil(rec_cap/1024) + 1 words     scan scratch; ends with the segment total
-//   seg_desc   max_segs x 16 B                   {first base offset, its quality offset, k-mers, 0}
+//   seg_desc   max_segs x 8 B                    {first base offset, its quality offset}
 //   planes     4 planes x plane_words words      v, h, l0, l1: one bit per byte of the chunk;
 //                                                plane_words >= ceil(len / 64) + 2
 #define QH_SEG_KMERS 12
 struct qh_fastq_aux {
   uint32_t* tile_sums;
-  uint4* seg_desc;
+  uint2* seg_desc;
   uint64_t* planes;
   uint64_t plane_words;
 };

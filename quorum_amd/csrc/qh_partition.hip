@@ -39,7 +39,9 @@
 // made by one streaming pass that knows nothing about records.
 //
 // SEGMENTS: up to QP_SEG consecutive k-mers of one read, the unit of work of one extraction lane:
-// {byte offset of the first base, byte offset of its quality, k-mers, 0}.
+// {byte offset of the first base, byte offset of its quality}. How many of the QP_SEG windows are k-mers of
+// the read is not stored: a window that runs past the read's last base covers the newline after it, which
+// is no base (a FASTQ sequence line is never the last line of its record).
 
 #define RB_TILE 1024  // records per scan tile
 #define QP_SEG 12     // k-mers per segment (= items a lane keeps in registers per tile)
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t* __restrict__ v, uin
 
 __global__ __launch_bounds__(256) void k_rec_segs_apply(const uint4* __restrict__ recs, const qh_meta* __restrict__ meta,
                                                         const uint32_t* __restrict__ tile_sums, uint32_t k,
-                                                        uint4* __restrict__ seg_desc) {
+                                                        uint2* __restrict__ seg_desc) {
   __shared__ uint32_t wtot[4];
   const uint32_t nrec = meta->format_err ? 0 : meta->nrec;
   const uint32_t base = blockIdx.x * RB_TILE;
@@ -100,11 +102,8 @@ __global__ __launch_bounds__(256) void k_rec_segs_apply(const uint4* __restrict_
     }
     if (cs) {
       // k-mers [a, a + n) of the read; k-mer i spans bases i .. i+k-1
-      const uint32_t ps = srun + swbase + sinc - cs, nk = rc.y - k + 1;
-      for (uint32_t b = 0; b < cs; ++b) {
-        const uint32_t a = b * QP_SEG, left = nk - a;
-        seg_desc[ps + b] = make_uint4(rc.x + a, rc.z + a, left < QP_SEG ? left : QP_SEG, 0);
-      }
+      const uint32_t ps = srun + swbase + sinc - cs;
+      for (uint32_t b = 0; b < cs; ++b) seg_desc[ps + b] = make_uint2(rc.x + b * QP_SEG, rc.z + b * QP_SEG);
     }
     srun += stot;
     __syncthreads();
@@ -157,7 +156,7 @@ struct qp_params {
   // SRC_FASTQ: the chunk as text planes + segment descriptors (qh_launch_text_planes / _segments)
   const uint64_t* planes;
   uint64_t plane_words;  // words per plane
-  const uint4* seg_desc;
+  const uint2* seg_desc;
   const uint32_t* seg_total;
   // SRC_ITEMS: input bucket b = blockIdx.y holds in[b * in_cap ...], in_counts[b] items (or in_n when in_counts == 0)
   const uint64_t* in;
@@ -212,18 +211,20 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
   // tile t is sorted and written out (one workgroup per CU: nothing else would hide the latency).
   // FASTQ: a lane per segment; its descriptor is fetched two tiles ahead, its two plane blocks
   // (64 bytes) one tile ahead.
-  uint4 sd_cur = make_uint4(0, 0, 0, 0), sd_next = make_uint4(0, 0, 0, 0);
+  const uint2 no_seg = make_uint2(~0u, ~0u);
+  uint2 sd_cur = no_seg, sd_next = no_seg;
   uint4 pl[4];  // words j, j+1 of the v, l0, l1 planes at the sequence offset and of h at the quality offset
   uint64_t raw[QP_BLOCKS_PER_WAVE];
-  auto load_sdesc = [&](uint64_t tile) -> uint4 {
+  auto load_sdesc = [&](uint64_t tile) -> uint2 {
     const uint64_t sidx = tile * QP_THREADS + tid;
-    return sidx < nseg ? p.seg_desc[sidx] : make_uint4(0, 0, 0, 0);
+    return sidx < nseg ? p.seg_desc[sidx] : no_seg;
   };
   auto load2 = [&](const uint64_t* q) -> uint4 {  // two consecutive words, 8-byte aligned
     const uint2 a = *reinterpret_cast<const uint2*>(q), b = *reinterpret_cast<const uint2*>(q + 1);
     return make_uint4(a.x, a.y, b.x, b.y);
   };
-  auto issue_planes = [&](const uint4& sd) {
+  auto issue_planes = [&](uint2 sd) {
+    if (sd.x == ~0u) sd = make_uint2(0, 0);  // no segment: any words will do
     const uint64_t* ps = p.planes + (sd.x >> 6);
     pl[0] = load2(ps);
     pl[1] = load2(ps + 2 * p.plane_words);
@@ -259,8 +260,8 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
       // create_database.cc:64-92 for the segment's k-mers: no rolling registers, every k-mer is a
       // k-bit window of the planes. w* hold bases a .. a+63 of the read (bit i = base a+i): v, l0, l1
       // from the sequence bytes, h from the quality bytes.
-      const uint32_t o = sd_cur.x & 63u, oq = sd_cur.y & 63u, cnt = sd_cur.z;
-      if (cnt) {
+      const uint32_t o = sd_cur.x & 63u, oq = sd_cur.y & 63u;
+      if (sd_cur.x != ~0u) {
         const uint32_t kones = (uint32_t)((1ull << g.k) - 1);
         auto fun = [&](const uint4& w2, uint32_t sh) -> uint64_t {
           const uint64_t lo = ((uint64_t)w2.y << 32) | w2.x, hi = ((uint64_t)w2.w << 32) | w2.z;
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
         const uint64_t f0 = __builtin_bitreverse64(w0) >> sh0, f1 = __builtin_bitreverse64(w1) >> sh0;
 #pragma unroll
         for (int j = 0; j < QP_SEG; ++j) {
-          if ((uint32_t)j < cnt && ((uint32_t)(wv >> j) & kones) == kones) {  // low_len >= k (:85)
+          if (((uint32_t)(wv >> j) & kones) == kones) {  // low_len >= k (:85); false past the read's end
             const uint32_t q = ((uint32_t)(wh >> j) & kones) == kones;         // high_len >= k (:86)
             const uint32_t r0 = ~(uint32_t)(w0 >> j) & kones, r1 = ~(uint32_t)(w1 >> j) & kones;
             const uint32_t m0 = (uint32_t)(f0 >> (QP_SEG - 1 - j)) & kones, m1 = (uint32_t)(f1 >> (QP_SEG - 1 - j)) & kones;
