@@ -99,39 +99,38 @@ __global__ __launch_bounds__(QH_BLOCK) void k_fill_records(const uint8_t* __rest
                                                            qh_meta* __restrict__ meta) {
   __shared__ uint32_t wtot[QH_BLOCK / 64];
   if (meta->format_err & (QH_FMT_LINES_MOD4 | QH_FMT_TOO_MANY)) return;
-  const size_t tile_base = (size_t)blockIdx.x * QH_TILE_BYTES;
-  uint32_t run = tile_prefix[blockIdx.x];
+  static_assert(QH_TILE_BYTES == QH_BLOCK * 4 * 16, "a thread takes four consecutive 16-byte units of the tile");
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll 1
+  // four consecutive units (64 bytes of text) per thread: one scan of the newline counts per tile
+  const size_t off0 = (size_t)blockIdx.x * QH_TILE_BYTES + (size_t)threadIdx.x * 64;
+  ushort4 nl[4];
+  uint32_t c = 0;
+#pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const size_t off = tile_base + ((size_t)j * QH_BLOCK + threadIdx.x) * 16;
-    const ushort4 nl = off < len ? nl_plane[off >> 4] : make_ushort4(0, 0, 0, 0);
-    uint32_t m = nl.x;
-    const uint32_t c = __popc(m);
-    // block exclusive scan of c
-    uint32_t inc = c;
+    nl[j] = off0 + (size_t)j * 16 < len ? nl_plane[(off0 >> 4) + j] : make_ushort4(0, 0, 0, 0);
+    c += __popc((uint32_t)nl[j].x);
+  }
+  uint32_t inc = c;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      uint32_t v = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += v;
-    }
-    if (lane == 63) wtot[wv] = inc;
-    __syncthreads();
-    uint32_t wbase = 0, tot = 0;
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t v = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += v;
+  }
+  if (lane == 63) wtot[wv] = inc;
+  __syncthreads();
+  uint32_t wbase = 0;
 #pragma unroll
-    for (int w = 0; w < QH_BLOCK / 64; ++w) {
-      const uint32_t x = wtot[w];
-      if (w < wv) wbase += x;
-      tot += x;
-    }
-    uint32_t L = run + wbase + inc - c;
+  for (int w = 0; w < QH_BLOCK / 64; ++w)
+    if (w < wv) wbase += wtot[w];
+  uint32_t L = tile_prefix[blockIdx.x] + wbase + inc - c;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t m = nl[j].x;
     while (m) {
       const int bpos = __ffs(m) - 1;
       m &= m - 1;
-      line_end(len, L++, (uint32_t)(off + bpos), (nl.y >> bpos) & 1, (nl.z >> bpos) & 1, recs, rec_cap, meta);
+      line_end(len, L++, (uint32_t)(off0 + (size_t)j * 16 + bpos), (nl[j].y >> bpos) & 1, (nl[j].z >> bpos) & 1, recs, rec_cap, meta);
     }
-    run += tot;
-    __syncthreads();
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && len > 0 && buf[len - 1] != '\n')
     line_end(len, meta->n_lines - 1, (uint32_t)len, true, true, recs, rec_cap, meta);
