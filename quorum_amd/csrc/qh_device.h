@@ -42,15 +42,24 @@ __device__ __forceinline__ uint32_t block_scan_u32(uint32_t* __restrict__ v, uin
   } else {
     for (uint32_t i = b; i < b + per && i < n; ++i) s += v[i];
   }
-  part[threadIdx.x] = s;
-  __syncthreads();
-  for (uint32_t o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan over the 1024 partials
-    const uint32_t x = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
-    __syncthreads();
-    part[threadIdx.x] += x;
-    __syncthreads();
+  // scan of the 1024 partials: inside each wave by shuffles, then the 16 wave totals through LDS
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += y;
   }
-  uint32_t run = part[threadIdx.x] - s;  // exclusive prefix of this thread's span
+  if (lane == 63) part[wave] = inc;
+  __syncthreads();
+  uint32_t wbase = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const uint32_t y = part[w];
+    if (w < wave) wbase += y;
+    total += y;
+  }
+  uint32_t run = wbase + inc - s;  // exclusive prefix of this thread's span
   if (small) {
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
@@ -64,7 +73,7 @@ __device__ __forceinline__ uint32_t block_scan_u32(uint32_t* __restrict__ v, uin
       run += x;
     }
   }
-  return part[1023];
+  return total;
 }
 
 // 16-bit mask of the bytes of v that equal '\n'
