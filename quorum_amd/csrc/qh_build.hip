@@ -363,12 +363,16 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
   const size_t cap1 = b2 ? max_items / ((size_t)1 << b1) + max_items / ((size_t)1 << b1) / 10 + 4096 : 0;
   int rc;
   if ((rc = ensure((void**)&h->d_bins[1], &h->bins_cap[1], (size_t)nw * capw * 8, "window buckets"))) return rc;
-  if ((rc = ensure((void**)&h->d_bin_counts[1], &h->bin_counts_cap[1], (size_t)nw * 8, "window bucket counts"))) return rc;
-  QH_HIP(hipMemsetAsync(h->d_bin_counts[1], 0, (size_t)nw * 8, h->stream));
+  // the counters are cleared by the segment kernel when there is one (FASTQ source), else by fills
+  const size_t wc_bytes = ((size_t)nw * 8 + 15) & ~(size_t)15, l1c_bytes = b2 ? (((size_t)8 << b1) * QH_COUNT_STRIDE + 15) & ~(size_t)15 : 0;
+  if ((rc = ensure((void**)&h->d_bin_counts[1], &h->bin_counts_cap[1], wc_bytes, "window bucket counts"))) return rc;
   if (b2) {
     if ((rc = ensure((void**)&h->d_bins[0], &h->bins_cap[0], ((size_t)cap1 << b1) * 8, "level-1 buckets"))) return rc;
-    if ((rc = ensure((void**)&h->d_bin_counts[0], &h->bin_counts_cap[0], ((size_t)8 << b1) * QH_COUNT_STRIDE, "level-1 bucket counts"))) return rc;
-    QH_HIP(hipMemsetAsync(h->d_bin_counts[0], 0, ((size_t)8 << b1) * QH_COUNT_STRIDE, h->stream));
+    if ((rc = ensure((void**)&h->d_bin_counts[0], &h->bin_counts_cap[0], l1c_bytes, "level-1 bucket counts"))) return rc;
+  }
+  if (!src.fastq) {
+    QH_HIP(hipMemsetAsync(h->d_bin_counts[1], 0, wc_bytes, h->stream));
+    if (b2) QH_HIP(hipMemsetAsync(h->d_bin_counts[0], 0, l1c_bytes, h->stream));
   }
   // spill list = the idle overflow buffer; failures of its direct insertion go to the active one
   const int cur = h->cur_ovf, other = cur ^ 1;
@@ -388,7 +392,8 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
     if ((rc = fastq_aux(h, src.fastq_len, src.rec_cap, src.max_bases, &aux))) return rc;
     timing_begin(h, 0);
     if (!src.planes_ready) qh_launch_text_planes(src.fastq, src.fastq_len, g, aux, h->stream);
-    qh_launch_segments(h->d_recs, (uint32_t)src.rec_cap, h->d_meta, g, aux, h->stream);
+    qh_launch_segments(h->d_recs, (uint32_t)src.rec_cap, h->d_meta, g, aux, h->d_bin_counts[1], wc_bytes,
+                       b2 ? h->d_bin_counts[0] : nullptr, l1c_bytes, h->stream);
     timing_end(h, 0);
     timing_begin(h, 1);
     qh_launch_partition_fastq(aux, (uint32_t)src.rec_cap, h->d_meta, g, l1_dst, check_owner, h->stream);
@@ -778,7 +783,7 @@ extern "C" int qh_build_extract_partitioned_device(qh_build* h, const void* dev_
   if ((rc = fastq_aux(h, len, rec_cap, len / 2, &aux))) return rc;
   qh_launch_index_fastq((const uint8_t*)dev_buf, len, h->d_tiles, h->d_nlplane, h->d_recs, (uint32_t)rec_cap, h->d_meta,
                         &aux, h->g.min_qual, h->stream);
-  qh_launch_segments(h->d_recs, (uint32_t)rec_cap, h->d_meta, h->g, aux, h->stream);
+  qh_launch_segments(h->d_recs, (uint32_t)rec_cap, h->d_meta, h->g, aux, nullptr, 0, nullptr, 0, h->stream);
   // bucket = owner shard = low shard_bits of the hash; a bucket that overflows is an error here
   qh_part_dst dst = {dev_out, cap_per_shard, (unsigned long long*)dev_counts, 0, h->g.shard_bits, 0, nullptr, 0, 1};
   timing_begin(h, 1);

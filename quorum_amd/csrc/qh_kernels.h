@@ -85,7 +85,8 @@ struct qh_fastq_aux {
 void qh_launch_text_planes(const uint8_t* buf, size_t len, const qh_geom& g, const qh_fastq_aux& a, hipStream_t s);
 // record table -> segment descriptors (3 small kernels)
 void qh_launch_segments(const uint4* recs, uint32_t rec_cap, const qh_meta* meta, const qh_geom& g,
-                        const qh_fastq_aux& a, hipStream_t s);
+                        const qh_fastq_aux& a, void* zero_a, size_t zero_a_bytes, void* zero_b, size_t zero_b_bytes,
+                        hipStream_t s);
 void qh_launch_partition_fastq(const qh_fastq_aux& a, uint32_t rec_cap, qh_meta* meta, const qh_geom& g,
                                const qh_part_dst& d, int check_owner, hipStream_t s);
 void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsigned long long* in_counts,

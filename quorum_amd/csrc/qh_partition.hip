@@ -52,9 +52,15 @@ __device__ __forceinline__ uint32_t rec_nsegs(uint32_t len, uint32_t k) {
 }
 
 // tile_sums: [0, ntiles) segments per tile of RB_TILE records; the scan leaves the total at [ntiles]
+// Also clears the bucket counters of the partition levels (zero_a, zero_b: 16-byte pieces): two fewer fill
+// launches of ~18 us each in front of the first partition kernel.
 __global__ __launch_bounds__(256) void k_rec_segs_sum(const uint4* __restrict__ recs, const qh_meta* __restrict__ meta,
-                                                      uint32_t* __restrict__ tile_sums, uint32_t k) {
+                                                      uint32_t* __restrict__ tile_sums, uint32_t k,
+                                                      uint4* __restrict__ zero_a, uint32_t na,
+                                                      uint4* __restrict__ zero_b, uint32_t nb) {
   __shared__ uint32_t ws[4];
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < na; i += gridDim.x * 256) zero_a[i] = make_uint4(0, 0, 0, 0);
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nb; i += gridDim.x * 256) zero_b[i] = make_uint4(0, 0, 0, 0);
   const uint32_t nrec = meta->format_err ? 0 : meta->nrec;
   const uint32_t base = blockIdx.x * RB_TILE;
   uint32_t t = 0;
@@ -130,9 +136,12 @@ void qh_launch_text_planes(const uint8_t* buf, size_t len, const qh_geom& g, con
 }
 
 void qh_launch_segments(const uint4* recs, uint32_t rec_cap, const qh_meta* meta, const qh_geom& g,
-                        const qh_fastq_aux& a, hipStream_t s) {
+                        const qh_fastq_aux& a, void* zero_a, size_t zero_a_bytes, void* zero_b, size_t zero_b_bytes,
+                        hipStream_t s) {
   const uint32_t ntiles = (rec_cap + RB_TILE - 1) / RB_TILE;
-  hipLaunchKernelGGL(k_rec_segs_sum, dim3(ntiles), dim3(256), 0, s, recs, meta, a.tile_sums, (uint32_t)g.k);
+  hipLaunchKernelGGL(k_rec_segs_sum, dim3(ntiles), dim3(256), 0, s, recs, meta, a.tile_sums, (uint32_t)g.k,
+                     static_cast<uint4*>(zero_a), (uint32_t)(zero_a_bytes / 16), static_cast<uint4*>(zero_b),
+                     (uint32_t)(zero_b_bytes / 16));
   hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, a.tile_sums, ntiles);
   hipLaunchKernelGGL(k_rec_segs_apply, dim3(ntiles), dim3(256), 0, s, recs, meta, a.tile_sums, (uint32_t)g.k, a.seg_desc);
 }
