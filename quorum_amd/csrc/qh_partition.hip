@@ -473,8 +473,8 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
                                                              int table_dirty, uint64_t* __restrict__ spill,
                                                              uint64_t spill_cap, qh_meta* __restrict__ meta) {
   __shared__ uint64_t win[1u << QH_WINDOW_BITS];
-  __shared__ uint64_t ring[QP_WAVES][QW_RING];
-  __shared__ uint32_t wnew[QP_WAVES];
+  __shared__ uint64_t ring[QP_WAVES][QW_RING];  // window + rings = half of the CU's LDS: two workgroups per CU
+  uint32_t* wnew = reinterpret_cast<uint32_t*>(&ring[0][0]);  // reused once the rings have drained
   const uint32_t w = blockIdx.x;
   uint64_t n = counts[w];
   if (n > cap) n = cap;
@@ -622,10 +622,11 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
     }
   }
   n_new = wave_sum_u32(n_new);
+  __syncthreads();  // every chain has ended: the window is final and the rings are free
   if (lane == 0) wnew[wave] = n_new;
-  __syncthreads();
 #pragma unroll
   for (uint32_t i = 0; i < nvec / QP_THREADS; ++i) tw[i * QP_THREADS + tid] = lw[i * QP_THREADS + tid];
+  __syncthreads();
   if (tid == 0) {
     uint32_t t = 0;
     for (int i = 0; i < QP_WAVES; ++i) t += wnew[i];
@@ -657,15 +658,15 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
 // and HBM each about half used), so the round is kept short: a 128-entry ring whose refill and next request
 // are one step, liveness folded into the probe counter, the increment decoded once per item.
 template <bool CB16>
-__global__ __launch_bounds__(QP_THREADS) void k_window_count(uint64_t* __restrict__ table, const qh_geom g,
+__global__ __launch_bounds__(QP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_window_count(uint64_t* __restrict__ table, const qh_geom g,
                                                              const uint64_t* __restrict__ items, uint64_t cap,
                                                              const unsigned long long* __restrict__ counts,
                                                              uint32_t n_windows, int table_dirty,
                                                              uint64_t* __restrict__ spill, uint64_t spill_cap,
                                                              qh_meta* __restrict__ meta, int cb_arg) {
   __shared__ uint64_t win[1u << QH_WINDOW_BITS];
-  __shared__ uint64_t ring[QP_WAVES][QW_RING];
-  __shared__ uint32_t wnew[QP_WAVES];
+  __shared__ uint64_t ring[QP_WAVES][QW_RING];  // window + rings = half of the CU's LDS: two workgroups per CU
+  uint32_t* wnew = reinterpret_cast<uint32_t*>(&ring[0][0]);  // reused after the last window
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -837,6 +838,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_count(uint64_t* __restric
     }
   }
   n_new = wave_sum_u32(n_new);
+  __syncthreads();  // the rings are free
   if (lane == 0) wnew[wave] = n_new;
   __syncthreads();
   if (tid == 0) {
@@ -858,7 +860,7 @@ void qh_launch_window_build(uint64_t* table, const qh_geom& g, const uint64_t* i
   if (fits && !(force && !strcmp(force, "cas"))) {
     // one workgroup per CU walks the windows (see the kernel): QH_WINDOW_GRID overrides the grid for A/B tests
     const char* gs = getenv("QH_WINDOW_GRID");
-    uint32_t grid = gs ? (uint32_t)atoi(gs) : 256u;
+    uint32_t grid = gs ? (uint32_t)atoi(gs) : 512u;
     if (grid == 0 || grid > n_windows) grid = n_windows;
     const bool cb16 = 65536ull > cap + g.max_val + 1 && !(force && !strcmp(force, "count"));  // "count": generic form
     if (cb16)

@@ -38,7 +38,7 @@
 #define QH_HD inline
 #endif
 
-#define QH_WINDOW_BITS 14          // 16384 slots = 128 KiB: one window fits a CU's LDS
+#define QH_WINDOW_BITS 13          // 8192 slots = 64 KiB: two windows (two workgroups) fit a CU's LDS
 #define QH_MIX_C1 0x9E3779B1u
 #define QH_MIX_C2 0x85EBCA77u
 #define QH_MIX_C3 0xC2B2AE3Du
