@@ -139,11 +139,11 @@ def main():
         dom = max(range(1 if partitioned else 0, 4), key=lambda i: avgs[i])
         kernel_avg_ms, klaunch = avgs[dom], ktimes[dom][1]
         # names as rocprofv3 prints them: k_partition<0, ...> = FASTQ source (level 1), k_partition<1, ...> = item source
-        # (the two bools: owner check, k < 4)
+        # (owner check; class of k: 0 is k >= 12)
         knames = ("segments(k_rec_segs_sum+k_scan_u32+k_rec_segs_apply)" if partitioned and world == 1
                   else "k_build_direct" if world == 1 else "k_insert_items",
-                  "k_partition<0, false, false>" if world == 1 else "k_partition<1, false, false> (level 1)",
-                  "k_partition<1, false, false>" if world == 1 else "k_partition<1, false, false> (level 2)",
+                  "k_partition<0, false, 0>" if world == 1 else "k_partition<1, false, 0> (level 1)",
+                  "k_partition<1, false, 0>" if world == 1 else "k_partition<1, false, 0> (level 2)",
                   "k_window_count<true>")  # the counting form with 16-bit counters at this geometry
         per_launch = st["instances"]                # this rank's insertions per launch of the dominant kernel
         achieved = per_launch * ALG_BYTES_PER_KMER / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0

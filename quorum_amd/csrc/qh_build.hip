@@ -253,6 +253,7 @@ extern "C" int qh_build_sync(qh_build* h) {
                       : (m.format_err & QH_FMT_NO_AT)        ? "a record does not start with '@'"
                       : (m.format_err & QH_FMT_NO_PLUS)      ? "a separator line does not start with '+'"
                       : (m.format_err & QH_FMT_LEN_MISMATCH) ? "sequence and quality lengths differ"
+                      : (m.format_err & QH_FMT_LINE_TOO_LONG) ? "a line of 256 MiB or more"
                                                              : "empty sequence";
     return qh_fail(QH_EFORMAT, "chunk is not strict 4-line FASTQ (%s, near record %u); nothing was inserted", why, m.first_bad);
   }

@@ -24,7 +24,7 @@ struct qh_meta {
 };
 
 enum { QH_FMT_LINES_MOD4 = 1, QH_FMT_NO_AT = 2, QH_FMT_NO_PLUS = 4, QH_FMT_LEN_MISMATCH = 8,
-       QH_FMT_TOO_MANY = 16, QH_FMT_EMPTY_TAIL = 32 };
+       QH_FMT_TOO_MANY = 16, QH_FMT_EMPTY_TAIL = 32, QH_FMT_LINE_TOO_LONG = 64 };
 
 #define QH_TILE_BYTES 16384u
 
@@ -71,7 +71,7 @@ struct qh_part_dst {
 #define QH_COUNT_STRIDE 513u
 // Per-chunk device arrays of the FASTQ source (qh_partition.hip):
 //   tile_sums  ceil(rec_cap/1024) + 1 words     scan scratch; ends with the segment total
-//   seg_desc   max_segs x 8 B                    {first base offset, its quality offset}
+//   seg_desc   max_segs x 8 B                    {first base offset, (distance to its quality) << 4 | k-mers}
 //   planes     4 planes x plane_words words      v, h, l0, l1: one bit per byte of the chunk;
 //                                                plane_words >= ceil(len / 64) + 2
 #define QH_SEG_KMERS 12
@@ -84,7 +84,7 @@ struct qh_fastq_aux {
 // chunk text -> bit planes (one streaming pass, no record knowledge)
 void qh_launch_text_planes(const uint8_t* buf, size_t len, const qh_geom& g, const qh_fastq_aux& a, hipStream_t s);
 // record table -> segment descriptors (3 small kernels)
-void qh_launch_segments(const uint4* recs, uint32_t rec_cap, const qh_meta* meta, const qh_geom& g,
+void qh_launch_segments(const uint4* recs, uint32_t rec_cap, qh_meta* meta, const qh_geom& g,
                         const qh_fastq_aux& a, void* zero_a, size_t zero_a_bytes, void* zero_b, size_t zero_b_bytes,
                         hipStream_t s);
 void qh_launch_partition_fastq(const qh_fastq_aux& a, uint32_t rec_cap, qh_meta* meta, const qh_geom& g,

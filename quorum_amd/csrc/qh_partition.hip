@@ -39,9 +39,10 @@
 // made by one streaming pass that knows nothing about records.
 //
 // SEGMENTS: up to QP_SEG consecutive k-mers of one read, the unit of work of one extraction lane:
-// {byte offset of the first base, byte offset of its quality}. How many of the QP_SEG windows are k-mers of
-// the read is not stored: a window that runs past the read's last base covers the newline after it, which
-// is no base (a FASTQ sequence line is never the last line of its record).
+// {byte offset of the first base, (distance to its quality byte) << 4 | k-mers}; all zero = no segment. For
+// k >= QP_SEG the extraction does not look at the count: a window that is not a k-mer of the read then
+// starts inside the read and runs over the newline after it, which is no base (a FASTQ sequence line is never
+// the last line of its record). Shorter windows can lie wholly behind that newline, in the quality string.
 
 #define RB_TILE 1024  // records per scan tile
 #define QP_SEG 12     // k-mers per segment (= items a lane keeps in registers per tile)
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t* __restrict__ v, uin
   if (threadIdx.x == 1023) v[n] = total;
 }
 
-__global__ __launch_bounds__(256) void k_rec_segs_apply(const uint4* __restrict__ recs, const qh_meta* __restrict__ meta,
+__global__ __launch_bounds__(256) void k_rec_segs_apply(const uint4* __restrict__ recs, qh_meta* __restrict__ meta,
                                                         const uint32_t* __restrict__ tile_sums, uint32_t k,
                                                         uint2* __restrict__ seg_desc) {
   __shared__ uint32_t wtot[4];
@@ -108,8 +109,17 @@ __global__ __launch_bounds__(256) void k_rec_segs_apply(const uint4* __restrict_
     }
     if (cs) {
       // k-mers [a, a + n) of the read; k-mer i spans bases i .. i+k-1
-      const uint32_t ps = srun + swbase + sinc - cs;
-      for (uint32_t b = 0; b < cs; ++b) seg_desc[ps + b] = make_uint2(rc.x + b * QP_SEG, rc.z + b * QP_SEG);
+      const uint32_t ps = srun + swbase + sinc - cs, nk = rc.y - k + 1;
+      uint32_t dist = rc.z - rc.x;  // bases, newline, separator line, newline
+      if (dist >> 28) {             // a line of 256 MiB
+        atomicOr(&meta->format_err, QH_FMT_LINE_TOO_LONG);
+        atomicMin(&meta->first_bad, r);
+        dist = 0;
+      }
+      for (uint32_t b = 0; b < cs; ++b) {
+        const uint32_t a = b * QP_SEG, left = nk - a;
+        seg_desc[ps + b] = make_uint2(rc.x + a, (dist << 4) | (left < QP_SEG ? left : QP_SEG));
+      }
     }
     srun += stot;
     __syncthreads();
@@ -135,7 +145,7 @@ void qh_launch_text_planes(const uint8_t* buf, size_t len, const qh_geom& g, con
                      a.plane_words * 4, g.min_qual);
 }
 
-void qh_launch_segments(const uint4* recs, uint32_t rec_cap, const qh_meta* meta, const qh_geom& g,
+void qh_launch_segments(const uint4* recs, uint32_t rec_cap, qh_meta* meta, const qh_geom& g,
                         const qh_fastq_aux& a, void* zero_a, size_t zero_a_bytes, void* zero_b, size_t zero_b_bytes,
                         hipStream_t s) {
   const uint32_t ntiles = (rec_cap + RB_TILE - 1) / RB_TILE;
@@ -184,9 +194,10 @@ __device__ __forceinline__ void qp_spill(const qp_params& p, uint64_t item) {
   else p.meta->ovf_lost = 1;
 }
 
-// OWNER: items are checked against the shard that owns them (p.check_owner); SMALLK: k < 4. Both are the same for
+// OWNER: items are checked against the shard that owns them (p.check_owner); KCLASS: 0 k >= QP_SEG, 1 shorter (the
+// segment's k-mer count is looked at), 2 k < 4 (no core in the hash). Both are the same for
 // every item of a launch, and the extraction loop is bound by the instructions it issues per k-mer.
-template <int SRC, bool OWNER, bool SMALLK>
+template <int SRC, bool OWNER, int KCLASS>
 __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, const qh_geom g) {
   __shared__ uint64_t sorted[QP_TILE_ITEMS];
   __shared__ uint32_t cursor[QP_MAX_BINS];  // histogram, then running placement cursor
@@ -220,7 +231,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
   // tile t is sorted and written out (one workgroup per CU: nothing else would hide the latency).
   // FASTQ: a lane per segment; its descriptor is fetched two tiles ahead, its two plane blocks
   // (64 bytes) one tile ahead.
-  const uint2 no_seg = make_uint2(~0u, ~0u);
+  const uint2 no_seg = make_uint2(0, 0);
   uint2 sd_cur = no_seg, sd_next = no_seg;
   uint4 pl[4];  // words j, j+1 of the v, l0, l1 planes at the sequence offset and of h at the quality offset
   uint64_t raw[QP_BLOCKS_PER_WAVE];
@@ -232,13 +243,12 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
     const uint2 a = *reinterpret_cast<const uint2*>(q), b = *reinterpret_cast<const uint2*>(q + 1);
     return make_uint4(a.x, a.y, b.x, b.y);
   };
-  auto issue_planes = [&](uint2 sd) {
-    if (sd.x == ~0u) sd = make_uint2(0, 0);  // no segment: any words will do
+  auto issue_planes = [&](uint2 sd) {  // no segment: the chunk's first words
     const uint64_t* ps = p.planes + (sd.x >> 6);
     pl[0] = load2(ps);
     pl[1] = load2(ps + 2 * p.plane_words);
     pl[2] = load2(ps + 3 * p.plane_words);
-    pl[3] = load2(p.planes + p.plane_words + (sd.y >> 6));
+    pl[3] = load2(p.planes + p.plane_words + ((sd.x + (sd.y >> 4)) >> 6));
   };
   auto issue_items = [&](uint64_t tile) {
     const uint64_t j0 = tile * QP_TILE_ITEMS + (uint64_t)wave * (QP_BLOCKS_PER_WAVE * 64) + lane;
@@ -269,8 +279,8 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
       // create_database.cc:64-92 for the segment's k-mers: no rolling registers, every k-mer is a
       // k-bit window of the planes. w* hold bases a .. a+63 of the read (bit i = base a+i): v, l0, l1
       // from the sequence bytes, h from the quality bytes.
-      const uint32_t o = sd_cur.x & 63u, oq = sd_cur.y & 63u;
-      if (sd_cur.x != ~0u) {
+      const uint32_t o = sd_cur.x & 63u, oq = (sd_cur.x + (sd_cur.y >> 4)) & 63u, cnt = sd_cur.y & 15u;
+      if (cnt) {
         const uint32_t kones = (uint32_t)((1ull << g.k) - 1);
         auto fun = [&](const uint4& w2, uint32_t sh) -> uint64_t {
           const uint64_t lo = ((uint64_t)w2.y << 32) | w2.x, hi = ((uint64_t)w2.w << 32) | w2.z;
@@ -283,11 +293,11 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
         const uint64_t f0 = __builtin_bitreverse64(w0) >> sh0, f1 = __builtin_bitreverse64(w1) >> sh0;
 #pragma unroll
         for (int j = 0; j < QP_SEG; ++j) {
-          if (((uint32_t)(wv >> j) & kones) == kones) {  // low_len >= k (:85); false past the read's end
+          if ((KCLASS == 0 || (uint32_t)j < cnt) && ((uint32_t)(wv >> j) & kones) == kones) {  // low_len >= k (:85)
             const uint32_t q = ((uint32_t)(wh >> j) & kones) == kones;         // high_len >= k (:86)
             const uint32_t r0 = ~(uint32_t)(w0 >> j) & kones, r1 = ~(uint32_t)(w1 >> j) & kones;
             const uint32_t m0 = (uint32_t)(f0 >> (QP_SEG - 1 - j)) & kones, m1 = (uint32_t)(f1 >> (QP_SEG - 1 - j)) & kones;
-            const uint64_t h = qh_hash_strands_form<SMALLK>(m0, m1, r0, r1, g.k);  // min(m, rm) of create_database.cc:86, hashed
+            const uint64_t h = qh_hash_strands_form<KCLASS == 2>(m0, m1, r0, r1, g.k);  // min(m, rm) of create_database.cc:86, hashed
             if (OWNER && ((uint32_t)h & smask) != (uint32_t)g.shard_id) {
               ++n_foreign;
             } else {
@@ -420,13 +430,18 @@ void qh_launch_partition_fastq(const qh_fastq_aux& a, uint32_t rec_cap, qh_meta*
   p.planes = a.planes; p.plane_words = a.plane_words; p.seg_desc = a.seg_desc;
   p.seg_total = a.tile_sums + (rec_cap + RB_TILE - 1) / RB_TILE;
   const dim3 grid(256), block(QP_THREADS);
-  if (g.k < 4) {
-    if (check_owner) hipLaunchKernelGGL((k_partition<QP_SRC_FASTQ, true, true>), grid, block, 0, s, p, g);
-    else hipLaunchKernelGGL((k_partition<QP_SRC_FASTQ, false, true>), grid, block, 0, s, p, g);
+  const int kclass = g.k < 4 ? 2 : g.k < QP_SEG ? 1 : 0;
+#define QP_LAUNCH_FASTQ(OWNER, KC) hipLaunchKernelGGL((k_partition<QP_SRC_FASTQ, OWNER, KC>), grid, block, 0, s, p, g)
+  if (check_owner) {
+    if (kclass == 2) QP_LAUNCH_FASTQ(true, 2);
+    else if (kclass == 1) QP_LAUNCH_FASTQ(true, 1);
+    else QP_LAUNCH_FASTQ(true, 0);
   } else {
-    if (check_owner) hipLaunchKernelGGL((k_partition<QP_SRC_FASTQ, true, false>), grid, block, 0, s, p, g);
-    else hipLaunchKernelGGL((k_partition<QP_SRC_FASTQ, false, false>), grid, block, 0, s, p, g);
+    if (kclass == 2) QP_LAUNCH_FASTQ(false, 2);
+    else if (kclass == 1) QP_LAUNCH_FASTQ(false, 1);
+    else QP_LAUNCH_FASTQ(false, 0);
   }
+#undef QP_LAUNCH_FASTQ
 }
 
 void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsigned long long* in_counts,
@@ -442,8 +457,8 @@ void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsign
   uint64_t gx = n_in_buckets >= 256 ? 1 : (256 + n_in_buckets - 1) / n_in_buckets * 2;
   if (gx > tiles) gx = tiles;
   const dim3 grid((unsigned)gx, n_in_buckets), block(QP_THREADS);
-  if (check_owner) hipLaunchKernelGGL((k_partition<QP_SRC_ITEMS, true, false>), grid, block, 0, s, p, g);
-  else hipLaunchKernelGGL((k_partition<QP_SRC_ITEMS, false, false>), grid, block, 0, s, p, g);
+  if (check_owner) hipLaunchKernelGGL((k_partition<QP_SRC_ITEMS, true, 0>), grid, block, 0, s, p, g);
+  else hipLaunchKernelGGL((k_partition<QP_SRC_ITEMS, false, 0>), grid, block, 0, s, p, g);
 }
 
 // ----------------------------------------------------------------- window build

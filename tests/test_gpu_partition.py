@@ -123,3 +123,25 @@ def test_modes_agree_at_full_size():
     (s0, (m0, v0)), (s1, (m1, v1)) = dumps
     assert s0["instances"] == s1["instances"] and s0["distinct"] == s1["distinct"] == m0.size
     assert (m0 == m1).all() and (v0 == v1).all()
+
+
+@pytest.mark.parametrize("k", [5, 9, 11, 12, 13])
+def test_short_k_quality_strings_that_look_like_bases(k):
+    """windows of fewer than 12 bases can lie wholly behind a read's newline, inside its quality string: with
+    qualities written in the letters A, C, G, T (all valid, high-quality characters) such a window must not
+    become a k-mer. Read lengths are ragged so that last segments hold 1..12 k-mers."""
+    rng = np.random.default_rng(500 + k)
+    recs = []
+    for i in range(3000):
+        n = int(rng.integers(k, k + 40))
+        seq = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n))
+        qual = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n))
+        recs.append(b"@read%d\n" % i + seq + b"\n+\n" + qual + b"\n")
+    data = b"".join(recs)
+    db = po.OracleDB(1 << 20, k, 7)
+    n = db.add_fastq(data, 38, threads=2)
+    om, ov = db.sorted_dump()
+    h, st, m, v = build(data, k, 7, 1 << 20, "partition")
+    assert st["instances"] == n and st["distinct"] == om.size
+    assert (m == om).all() and (v == ov).all()
+    h.close()
