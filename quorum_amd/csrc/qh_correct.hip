@@ -864,9 +864,15 @@ __global__ __launch_bounds__(EC_FMT_BLOCK) void k_ec_block_sums(const uint32_t* 
                                                                 unsigned long long* __restrict__ bsums) {
   __shared__ unsigned long long sh[2][EC_FMT_BLOCK / 64];
   const uint32_t nrec = meta->format_err ? 0u : meta->nrec;
+  // the grid is sized from the chunk length (~13 times the blocks that hold records); nobody reads the sums of
+  // the others (k_ec_scan_blocks and k_ec_format stop at nrec)
+  if (blockIdx.x * EC_FMT_BLOCK >= nrec) return;
   const uint32_t r = blockIdx.x * EC_FMT_BLOCK + threadIdx.x;
   uint32_t a = 0, b = 0;
-  if (r < nrec) { a = res[(size_t)r * EC_RES_WORDS + 6]; b = res[(size_t)r * EC_RES_WORDS + 7]; }
+  if (r < nrec) {
+    const uint2 ab = *reinterpret_cast<const uint2*>(res + (size_t)r * EC_RES_WORDS + 6);
+    a = ab.x; b = ab.y;
+  }
   // per-read sizes are < 2^32 / 64 in any chunk the library accepts (chunk <= 4 GB), sum in 64 bits anyway
   unsigned long long sa = a, sb = b;
 #pragma unroll
@@ -1018,12 +1024,29 @@ __global__ __launch_bounds__(EC_FMT_BLOCK) void k_ec_format(const uint8_t* __res
   __syncthreads();
   // corrected bases: wave w copies the sequences of reads 64 w .. 64 w + 63, 64 bytes per step
   const uint32_t lane = tid & 63u, w0 = tid & ~63u;
-  for (uint32_t i = 0; i < 64; ++i) {
-    const uint32_t n = cp_n[w0 + i];
-    if (!n) continue;
-    const uint8_t* __restrict__ src = obuf + cp_src[w0 + i];
-    uint8_t* dst = text + mis + cp_dst[w0 + i];
-    for (uint32_t b = lane; b < n; b += 64) dst[b] = src[b];
+  // (eight reads at a time, so that their loads are in flight together: one read after the other, each load
+  // waited for, made this loop the whole kernel's time)
+  for (uint32_t i0 = 0; i0 < 64; i0 += 8) {
+    uint32_t n[8], a[8], b[8];
+    const uint8_t* src[8];
+    uint8_t* dst[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      n[u] = cp_n[w0 + i0 + u];
+      src[u] = obuf + cp_src[w0 + i0 + u];
+      dst[u] = text + mis + cp_dst[w0 + i0 + u];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a[u] = lane < n[u] ? src[u][lane] : 0u;
+      b[u] = lane + 64u < n[u] ? src[u][lane + 64u] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (lane < n[u]) dst[u][lane] = (uint8_t)a[u];
+      if (lane + 64u < n[u]) dst[u][lane + 64u] = (uint8_t)b[u];
+      for (uint32_t x = lane + 128u; x < n[u]; x += 64) dst[u][x] = src[u][x];  // reads of more than 128 bases
+    }
   }
   __syncthreads();
   // stream the block's text out: whole 16-byte units as one store, the ragged ends byte by byte
