@@ -39,10 +39,10 @@
 // made by one streaming pass that knows nothing about records.
 //
 // SEGMENTS: up to QP_SEG consecutive k-mers of one read, the unit of work of one extraction lane:
-// {byte offset of the first base, (distance to its quality byte) << 4 | k-mers}; all zero = no segment. For
-// k >= QP_SEG the extraction does not look at the count: a window that is not a k-mer of the read then
-// starts inside the read and runs over the newline after it, which is no base (a FASTQ sequence line is never
-// the last line of its record). Shorter windows can lie wholly behind that newline, in the quality string.
+// {byte offset of the first base, (distance to its quality byte) << 4 | k-mers}; all zero = no segment. A read's
+// k-mers are spread evenly over its segments. The count matters: a window past it is a k-mer of the next
+// segment, or runs over the newline after the read (no base) or, for k < QP_SEG, can even lie wholly behind
+// that newline, inside the quality string, whose letters may all be A, C, G, T.
 
 #define RB_TILE 1024  // records per scan tile
 #define QP_SEG 12     // k-mers per segment (= items a lane keeps in registers per tile)
@@ -116,9 +116,12 @@ __global__ __launch_bounds__(256) void k_rec_segs_apply(const uint4* __restrict_
         atomicMin(&meta->first_bad, r);
         dist = 0;
       }
+      // the read's k-mers in cs segments of equal size (+1 for the first few): the lanes of a wave then run the
+      // same number of windows (77 k-mers are 7 x 11, not 6 x 12 + 5)
+      const uint32_t each = nk / cs, more = nk - each * cs;
       for (uint32_t b = 0; b < cs; ++b) {
-        const uint32_t a = b * QP_SEG, left = nk - a;
-        seg_desc[ps + b] = make_uint2(rc.x + a, (dist << 4) | (left < QP_SEG ? left : QP_SEG));
+        const uint32_t a = b * each + (b < more ? b : more);
+        seg_desc[ps + b] = make_uint2(rc.x + a, (dist << 4) | (each + (b < more ? 1u : 0u)));
       }
     }
     srun += stot;
@@ -194,8 +197,8 @@ __device__ __forceinline__ void qp_spill(const qp_params& p, uint64_t item) {
   else p.meta->ovf_lost = 1;
 }
 
-// OWNER: items are checked against the shard that owns them (p.check_owner); KCLASS: 0 k >= QP_SEG, 1 shorter (the
-// segment's k-mer count is looked at), 2 k < 4 (no core in the hash). Both are the same for
+// OWNER: items are checked against the shard that owns them (p.check_owner); KCLASS: 2 is k < 4 (no core in the
+// hash; 0 and 1 are compiled alike). Both are the same for
 // every item of a launch, and the extraction loop is bound by the instructions it issues per k-mer.
 template <int SRC, bool OWNER, int KCLASS>
 __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, const qh_geom g) {
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
         const uint64_t f0 = __builtin_bitreverse64(w0) >> sh0, f1 = __builtin_bitreverse64(w1) >> sh0;
 #pragma unroll
         for (int j = 0; j < QP_SEG; ++j) {
-          if ((KCLASS == 0 || (uint32_t)j < cnt) && ((uint32_t)(wv >> j) & kones) == kones) {  // low_len >= k (:85)
+          if ((uint32_t)j < cnt && ((uint32_t)(wv >> j) & kones) == kones) {  // low_len >= k (:85)
             const uint32_t q = ((uint32_t)(wh >> j) & kones) == kones;         // high_len >= k (:86)
             const uint32_t r0 = ~(uint32_t)(w0 >> j) & kones, r1 = ~(uint32_t)(w1 >> j) & kones;
             const uint32_t m0 = (uint32_t)(f0 >> (QP_SEG - 1 - j)) & kones, m1 = (uint32_t)(f1 >> (QP_SEG - 1 - j)) & kones;
