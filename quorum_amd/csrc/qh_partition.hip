@@ -289,14 +289,15 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
           const uint64_t lo = ((uint64_t)w2.y << 32) | w2.x, hi = ((uint64_t)w2.w << 32) | w2.z;
           return (lo >> sh) | ((hi << 1) << (63 - sh));
         };
-        const uint64_t wv = fun(pl[0], o), w0 = fun(pl[1], o), w1 = fun(pl[2], o), wh = fun(pl[3], oq);
+        // bases past the segment's last k-mer count as no bases: the windows past its count are then invalid
+        const uint64_t wv = fun(pl[0], o) & ((1ull << (cnt + g.k - 1)) - 1), w0 = fun(pl[1], o), w1 = fun(pl[2], o), wh = fun(pl[3], oq);
         // forward orientation: bit-reversed planes, aligned so that the newest base of k-mer j sits
         // at bit QP_SEG-1-j
         const int sh0 = 64 - g.k - (QP_SEG - 1);
         const uint64_t f0 = __builtin_bitreverse64(w0) >> sh0, f1 = __builtin_bitreverse64(w1) >> sh0;
 #pragma unroll
         for (int j = 0; j < QP_SEG; ++j) {
-          if ((uint32_t)j < cnt && ((uint32_t)(wv >> j) & kones) == kones) {  // low_len >= k (:85)
+          if (((uint32_t)(wv >> j) & kones) == kones) {  // low_len >= k (:85), and j < cnt
             const uint32_t q = ((uint32_t)(wh >> j) & kones) == kones;         // high_len >= k (:86)
             const uint32_t r0 = ~(uint32_t)(w0 >> j) & kones, r1 = ~(uint32_t)(w1 >> j) & kones;
             const uint32_t m0 = (uint32_t)(f0 >> (QP_SEG - 1 - j)) & kones, m1 = (uint32_t)(f1 >> (QP_SEG - 1 - j)) & kones;
