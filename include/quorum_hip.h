@@ -119,6 +119,18 @@ int qh_build_add_mers_device(qh_build* h, const uint64_t* dev_items, size_t n);
 /* same for items produced by qh_build_extract_partitioned_device (hashed form) */
 int qh_build_add_hashed_device(qh_build* h, const uint64_t* dev_items, size_t n);
 
+/* qh_build_add_mers_device for callers that cannot allocate. NO counterpart in the reference: it exists
+ * for code that must not reach hipMalloc (tight serving loops, harnesses that forbid allocation, code
+ * around HIP graph capture). Same items, same update rule, same table as qh_build_add_mers_device; the
+ * kernel's counters and overflow queue live in a file-scope device array of 512.25 KiB that every GPU
+ * the library runs on holds until the process ends, so the call performs no hipMalloc / hipFree.
+ * Limits: n <= 2^24 items per call (QH_EBADARG beyond); the table cannot grow here, so an item that hits
+ * the reprobe limit makes the call (and the handle) fail with QH_EFULL: size the table at creation.
+ * No chunk of another entry point may be in flight (call qh_build_sync first). The call returns when the
+ * items are in the table. All calls on one GPU share that GPU's array: calls that overlap on one GPU
+ * (from two threads or two handles) race. */
+int qh_build_add_mers_device_noalloc(qh_build* h, const uint64_t* dev_items, size_t n);
+
 /* Waits for queued work, performs table doubling when a chunk overflowed
  * (the role of handle_full_ary, src/mer_database.hpp:137-187) and returns the
  * first deferred error: QH_EFULL (growth impossible), QH_EFORMAT, QH_EHIP. */

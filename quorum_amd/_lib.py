@@ -67,6 +67,7 @@ SIGNATURES = [
     ("qh_build_add_mers", C.c_int, [_p, _u64p, _u8p, C.c_size_t]),
     ("qh_build_add_mers_device", C.c_int, [_p, _p, C.c_size_t]),
     ("qh_build_add_hashed_device", C.c_int, [_p, _p, C.c_size_t]),
+    ("qh_build_add_mers_device_noalloc", C.c_int, [_p, _p, C.c_size_t]),
     ("qh_detect_min_qual_char", C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
     ("qh_mer_hash", C.c_int, [C.c_int, _u64p, C.c_size_t, _u64p]),
     ("qh_host_alloc", C.c_int, [C.POINTER(_p), C.c_size_t]),

@@ -8,6 +8,7 @@
 #include <unistd.h>
 #include <fcntl.h>
 #include <errno.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,41 @@ int qh_fail(int status, const char* fmt, ...) {
 
 extern "C" const char* qh_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char* qh_version(void) { return "quorum_hip 0.1 (gfx950)"; }
+
+// ------------------------------------------- scratch of the no-allocation entry point
+//
+// qh_build_add_mers_device_noalloc (end of this file) runs k_insert_items with its counters and its
+// overflow queue in this file-scope array instead of the handle's hipMalloc'ed d_meta / d_ovf.
+// Layout: [qh_meta, padded to 256 bytes][QH_NOALLOC_QUEUE_ITEMS items]. Every GPU holds its own copy
+// at its own address: the array's NAME is only a host-side stand-in, host code uses the address
+// hipGetSymbolAddress returned for the device (g_scratch_ptr), resolved once per device in qh_build_create.
+#define QH_NOALLOC_MAX_ITEMS (1ull << 24)   // items per call
+#define QH_NOALLOC_QUEUE_ITEMS (1u << 16)   // overflow queue: 512 KiB
+#define QH_NOALLOC_META_BYTES 256u
+#define QH_NOALLOC_SCRATCH_BYTES (QH_NOALLOC_META_BYTES + 8u * QH_NOALLOC_QUEUE_ITEMS)
+static_assert(sizeof(qh_meta) <= QH_NOALLOC_META_BYTES, "qh_meta must fit the head of the scratch array");
+static __device__ __align__(256) unsigned char scratch[QH_NOALLOC_SCRATCH_BYTES];
+
+#define QH_MAX_DEVICES 64
+static std::mutex g_scratch_mu;
+static void* g_scratch_ptr[QH_MAX_DEVICES];  // device address of `scratch` on each device, 0 = not resolved yet
+
+// with `device` current: the address of this device's copy of the scratch array
+static int scratch_resolve(int device, void** out) {
+  if (device < 0 || device >= QH_MAX_DEVICES) return qh_fail(QH_EBADARG, "device id %d out of range", device);
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!g_scratch_ptr[device]) {
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) {
+      (void)hipGetLastError();
+      return qh_fail(QH_EHIP, "hipGetSymbolAddress(scratch) failed on device %d: %s", device, hipGetErrorString(e));
+    }
+    g_scratch_ptr[device] = p;
+  }
+  *out = g_scratch_ptr[device];
+  return QH_OK;
+}
 
 // ----------------------------------------------------------------- geometry
 
@@ -115,6 +151,7 @@ extern "C" int qh_build_create(qh_build** out, int k, int bits, uint64_t size, i
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return qh_fail(QH_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
   h->own_stream = h->stream;
+  { int src = scratch_resolve(device, &h->noalloc_scratch); if (src) { qh_build_destroy(h); return src; } }
   const size_t bytes = (size_t)8 << g.lsize;
   e = hipMalloc((void**)&h->table, bytes);
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_meta, sizeof(qh_meta));
@@ -797,6 +834,53 @@ extern "C" int qh_build_extract_partitioned_device(qh_build* h, const void* dev_
   if (h->h_meta->format_err) return qh_fail(QH_EFORMAT, "chunk is not strict 4-line FASTQ (flags 0x%x near record %u)", h->h_meta->format_err, h->h_meta->first_bad);
   if (h->h_meta->ovf_lost) return qh_fail(QH_EBADARG, "cap_per_shard too small for this chunk");
   h->st.records += h->h_meta->nrec;
+  return QH_OK;
+}
+
+// The no-allocation variant of qh_build_add_mers_device (no counterpart in the reference): the same
+// k_insert_items launch, with the kernel's counters (qh_meta) and overflow queue in this device's copy of
+// the file-scope `scratch` array instead of buffers that ensure() would hipMalloc. Nothing here allocates:
+// the table, the stream and the pinned meta mirror were made by qh_build_create. The call completes before
+// it returns (the counters are read back), and a table that would have to grow is an error: growth allocates.
+extern "C" int qh_build_add_mers_device_noalloc(qh_build* h, const uint64_t* dev_items, size_t n) {
+  if (!h) return qh_fail(QH_EBADARG, "null handle");
+  if (h->failed) return qh_fail(h->failed, "%s", h->failed_msg.c_str());
+  if (n == 0) return QH_OK;
+  if (!dev_items) return qh_fail(QH_EBADARG, "null items");
+  if (n > QH_NOALLOC_MAX_ITEMS)
+    return qh_fail(QH_EBADARG, "qh_build_add_mers_device_noalloc takes at most %llu items per call (got %zu)",
+                   (unsigned long long)QH_NOALLOC_MAX_ITEMS, n);
+  if (h->pending)
+    return qh_fail(QH_EBADARG, "a chunk of another entry point is in flight: call qh_build_sync first "
+                               "(collecting it may have to grow the table, which allocates)");
+  if (!h->noalloc_scratch) return qh_fail(QH_EHIP, "the scratch array was not resolved on device %d", h->device);
+  QH_HIP(hipSetDevice(h->device));
+  int rc = materialize(h);  // a memset of the existing table at most
+  if (rc) return rc;
+  // the device address from hipGetSymbolAddress, never the array's name
+  unsigned char* base = static_cast<unsigned char*>(h->noalloc_scratch);
+  qh_meta* meta = reinterpret_cast<qh_meta*>(base);
+  uint64_t* queue = reinterpret_cast<uint64_t*>(base + QH_NOALLOC_META_BYTES);
+  // the array keeps the last call's contents: the counters must start at zero (the queue is only read
+  // below its fresh count)
+  QH_HIP(hipMemsetAsync(meta, 0, QH_NOALLOC_META_BYTES, h->stream));
+  qh_launch_insert_items(dev_items, n, nullptr, 1, 0, meta, h->g, h->table, queue, QH_NOALLOC_QUEUE_ITEMS, h->stream);
+  QH_HIP(hipGetLastError());
+  QH_HIP(hipMemcpyAsync(h->h_meta, meta, sizeof(qh_meta), hipMemcpyDeviceToHost, h->stream));
+  QH_HIP(hipStreamSynchronize(h->stream));
+  h->table_dirty = true;
+  const qh_meta m = *h->h_meta;
+  h->st.instances += m.instances;
+  h->st.hq_instances += m.hq_instances;
+  h->st.distinct += m.new_keys;
+  h->st.foreign += m.foreign;
+  if (m.ovf_lost || m.ovf_count) {  // the queued items are not in the table and growing it would allocate
+    h->failed = qh_fail(QH_EFULL, "Hash is full (%llu items hit the reprobe limit; the no-allocation entry point "
+                                  "cannot grow the table: create it large enough)",
+                        (unsigned long long)m.ovf_count);
+    h->failed_msg = g_last_error;
+    return h->failed;
+  }
   return QH_OK;
 }
 

@@ -42,6 +42,7 @@ struct qh_build {
   bool evk_pending[4] = {false, false, false, false};
   double kernel_ms[4] = {0, 0, 0, 0};        // 0 direct/insert, 1 partition L1 (+extraction), 2 partition L2, 3 window build
   uint64_t kernel_launches[4] = {0, 0, 0, 0};
+  void* noalloc_scratch = nullptr;  // this device's copy of qh_build.hip's file-scope scratch array
   int failed = 0;             // sticky fatal status (QH_EFULL ...)
   std::string failed_msg;
 };

@@ -111,6 +111,11 @@ class HashWithQuality:
     def add_mers_device(self, dev_ptr, n):
         check(lib.qh_build_add_mers_device(self._h, C.c_void_p(dev_ptr), n))
 
+    def add_mers_device_noalloc(self, dev_ptr, n):
+        """qh_build_add_mers_device without any allocation (counters and overflow queue in the library's
+        file-scope device array; at most 2^24 items; the table cannot grow)"""
+        check(lib.qh_build_add_mers_device_noalloc(self._h, C.c_void_p(dev_ptr), n))
+
     def add_hashed_device(self, dev_ptr, n):
         """items in the library's hashed exchange form (qh_build_extract_partitioned_device)"""
         check(lib.qh_build_add_hashed_device(self._h, C.c_void_p(dev_ptr), n))
