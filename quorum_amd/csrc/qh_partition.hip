@@ -20,6 +20,7 @@
 #include "qh_device.h"
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 #define QP_THREADS 1024
 #define QP_WAVES (QP_THREADS / 64)
@@ -668,7 +669,8 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
 // Withdrawn increments are only ever visible in the counter fields, which nobody reads before the
 // final barrier, and counters cannot reach the tag (2^cb > bucket capacity + max count, checked
 // by the launcher). The words are converted from / to the table's [tag | count << 1 | hq] form
-// when the window is loaded / stored. Used when tag bits + 2 * cb fit 64 with cb >= 16; other
+// when the window is loaded / stored. Used when tag bits + 2 * cb fit 64 with 2^cb above the bucket
+// capacity (k = 31 reaches that at the table sizes of BASELINE configs[3]: 35 tag bits, cb = 14); other
 // geometries take k_window_build.
 //
 // CB16: cb == 16, i.e. the tag is the high word and both counters lie in the low word (no counter carry ever
@@ -683,6 +685,7 @@ __global__ __launch_bounds__(QP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
                                                              uint32_t n_windows, int table_dirty,
                                                              uint64_t* __restrict__ spill, uint64_t spill_cap,
                                                              qh_meta* __restrict__ meta, int cb_arg) {
+  typedef typename std::conditional<CB16, uint32_t, uint64_t>::type tag_t;  // tag = remainder | probe + 1
   __shared__ uint64_t win[1u << QH_WINDOW_BITS];
   __shared__ uint64_t ring[QP_WAVES][QW_RING];  // window + rings = half of the CU's LDS: two workgroups per CU
   uint32_t* wnew = reinterpret_cast<uint32_t*>(&ring[0][0]);  // reused after the last window
@@ -690,7 +693,7 @@ __global__ __launch_bounds__(QP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   const int cb = CB16 ? 16 : cb_arg;
-  const int tagshift = 2 * cb;  // >= 32
+  const int tagshift = 2 * cb;
   const uint64_t cmask = (1ull << cb) - 1;
   uint4* lw = reinterpret_cast<uint4*>(win);
   const uint32_t nvec = (1u << QH_WINDOW_BITS) / 2;  // 16-byte pieces
@@ -759,18 +762,21 @@ __global__ __launch_bounds__(QP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     // which the next 64 are queued (0 once the segment has ended)
     uint32_t head = 0, tail = 0, gate = seg_n ? 64 : 0;
     // chain state: tag at this probe, position, increment (1, or 1 << cb with quality), probes left (< 0: no chain)
-    uint32_t T = 0, pos = 0, inc = 1;
+    tag_t T = 0;
+    uint32_t pos = 0, inc = 1;
     int left = -1;
 
     for (;;) {
       uint32_t avail = tail - head;
       if (avail < gate) {
-        // decoded once, with every lane busy: {position | log2(increment) << 16, tag at probe 0}
+        // decoded once, with every lane busy. 16-bit counters: {tag at probe 0 : 32 | log2(increment) << 16 | position};
+        // wide tags: {tag at probe 0 : up to 50 | quality : 1 | position : QH_WINDOW_BITS}
         const uint64_t h = pend >> 1;
         const uint32_t p0 = (uint32_t)(h >> g.shard_bits) & wmask;
-        const uint32_t t0 = ((uint32_t)(gsize >= 64 ? 0 : (h >> gsize)) << g.pbits) | 1u;
+        const uint64_t t0 = ((gsize >= 64 ? 0 : (h >> gsize)) << g.pbits) | 1u;
         const uint32_t sh = (uint32_t)pend & 1u ? (uint32_t)cb : 0u;
-        myring[(tail + lane) & (QW_RING - 1)] = ((uint64_t)t0 << 32) | p0 | (sh << 16);
+        myring[(tail + lane) & (QW_RING - 1)] =
+            CB16 ? ((t0 << 32) | p0 | (sh << 16)) : ((t0 << (QH_WINDOW_BITS + 1)) | ((pend & 1u) << QH_WINDOW_BITS) | p0);
         tail += seg_n - tail < 64 ? seg_n - tail : 64;
         if (tail < seg_n) pend = tail + lane < seg_n ? src[tail + lane] : QP_NONE;
         else gate = 0;
@@ -787,9 +793,14 @@ __global__ __launch_bounds__(QP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         if (left < 0 && rank < give) {
           const uint64_t e = __hip_atomic_load(&myring[(head + rank) & (QW_RING - 1)], __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_WORKGROUP);
-          T = (uint32_t)(e >> 32);
+          if (CB16) {
+            T = (tag_t)(e >> 32);
+            inc = 1u << (((uint32_t)e >> 16) & 31u);
+          } else {
+            T = (tag_t)(e >> (QH_WINDOW_BITS + 1));
+            inc = ((uint32_t)e >> QH_WINDOW_BITS) & 1u ? 1u << cb : 1u;
+          }
           pos = (uint32_t)e & wmask;
-          inc = 1u << (((uint32_t)e >> 16) & 31u);
           left = (int)g.max_reprobe;
         }
         head += give;
@@ -797,7 +808,7 @@ __global__ __launch_bounds__(QP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
       if (left >= 0) {
         unsigned long long* slot = reinterpret_cast<unsigned long long*>(&win[pos]);
         const uint64_t old = atomicAdd(slot, (unsigned long long)inc);
-        uint32_t t = CB16 ? (uint32_t)(old >> 32) : (uint32_t)(old >> tagshift);
+        tag_t t = CB16 ? (tag_t)(old >> 32) : (tag_t)(old >> tagshift);
         if (t == 0) {  // a free slot: claim it, sighting included
           // Tried again in place while only counters move: every failure is then another chain's add or
           // withdrawal, of which there are finitely many. (Withdrawing and coming back in the next round
@@ -808,13 +819,13 @@ __global__ __launch_bounds__(QP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
           };
           uint64_t prev = atomicCAS(slot, (unsigned long long)expect, (unsigned long long)mine(expect));
           bool claimed = prev == expect;
-          t = CB16 ? (uint32_t)(prev >> 32) : (uint32_t)(prev >> tagshift);
+          t = CB16 ? (tag_t)(prev >> 32) : (tag_t)(prev >> tagshift);
           if (__builtin_expect(!claimed && t == 0, 0)) {
             do {
               expect = prev;
               prev = atomicCAS(slot, (unsigned long long)expect, (unsigned long long)mine(expect));
               claimed = prev == expect;
-              t = CB16 ? (uint32_t)(prev >> 32) : (uint32_t)(prev >> tagshift);
+              t = CB16 ? (tag_t)(prev >> 32) : (tag_t)(prev >> tagshift);
             } while (!claimed && t == 0);
           }
           if (claimed) {
@@ -829,7 +840,7 @@ __global__ __launch_bounds__(QP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
           __hip_atomic_fetch_sub(slot, (unsigned long long)inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           {
             if (left == 0) {  // reprobe limit: leave it to the direct path
-              const uint32_t probe = (T & ((1u << g.pbits) - 1)) - 1;
+              const uint32_t probe = ((uint32_t)T & ((1u << g.pbits) - 1)) - 1;
               const uint64_t home = ((uint64_t)w << QH_WINDOW_BITS) | ((pos - probe) & wmask);
               const uint64_t h = (gsize >= 64 ? 0 : ((uint64_t)(T >> g.pbits) << gsize)) | (home << g.shard_bits) |
                                  (uint64_t)g.shard_id;
@@ -875,13 +886,15 @@ void qh_launch_window_build(uint64_t* table, const qh_geom& g, const uint64_t* i
   const int tagbits = g.rbits + g.pbits;
   int cb = (64 - tagbits) / 2;
   if (cb > 31) cb = 31;
-  const bool fits = tagbits <= 32 && cb >= 16 && (1ull << cb) > cap + g.max_val + 1;
+  // (the tag must also fit a ring entry beside the position and the quality bit; 2^cb > max_val is implied)
+  const bool fits = tagbits <= 64 - (QH_WINDOW_BITS + 1) && cb >= 10 && (1ull << cb) > cap + g.max_val + 1;
   if (fits && !(force && !strcmp(force, "cas"))) {
     // one workgroup per CU walks the windows (see the kernel): QH_WINDOW_GRID overrides the grid for A/B tests
     const char* gs = getenv("QH_WINDOW_GRID");
     uint32_t grid = gs ? (uint32_t)atoi(gs) : 512u;
     if (grid == 0 || grid > n_windows) grid = n_windows;
-    const bool cb16 = 65536ull > cap + g.max_val + 1 && !(force && !strcmp(force, "count"));  // "count": generic form
+    // 16-bit counters: the tag is the high word ("count": the generic form even then)
+    const bool cb16 = tagbits <= 32 && 65536ull > cap + g.max_val + 1 && !(force && !strcmp(force, "count"));
     if (cb16)
       hipLaunchKernelGGL(k_window_count<true>, dim3(grid), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
                          n_windows, table_dirty, spill, spill_cap, meta, 16);

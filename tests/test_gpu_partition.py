@@ -11,10 +11,22 @@ from helpers import random_fastq, sorted_pairs, dict_model_np
 
 pytestmark = pytest.mark.gpu
 
+# Liveness guard of the window kernels. A claim that is withdrawn and retried in the NEXT round instead of in place
+# lets two waves in step fail each other's compare-and-swap for seconds (launches of 5 s and 23 s were measured,
+# DESIGN section 6) while every result stays correct: a parity test alone would pass, slowly. At these sizes a
+# healthy window pass takes well under a millisecond per chunk.
+WINDOW_PASS_BOUND_MS = 50.0
+
+
+def assert_window_pass_is_live(h, what):
+    ms, launches = h.kernel_time(3)
+    assert launches > 0 and ms < WINDOW_PASS_BOUND_MS, "%s: %d window passes took %.1f ms" % (what, launches, ms)
+
 
 def build(data, k, bits, size, mode, level1_bits=-1, chunks=1, thresh=38, **kw):
     h = qa.HashWithQuality(size, 2 * k, bits, min_qual=thresh, **kw)
     h.set_mode(mode, level1_bits)
+    h.enable_timing(True)
     if chunks == 1:
         h.add_fastq(data)
     else:
@@ -43,7 +55,7 @@ def test_partitioned_matches_oracle(size, level1_bits, chunks, k, bits):
     assert (m2 == om).all() and (v2 == ov).all()
 
 
-@pytest.mark.parametrize("k,bits,size", [(12, 2, 1 << 18), (16, 7, 1 << 20), (24, 3, 1 << 26)])
+@pytest.mark.parametrize("k,bits,size", [(12, 2, 1 << 18), (16, 7, 1 << 20), (24, 3, 1 << 26), (31, 3, 1 << 26)])
 def test_window_kernels_agree(k, bits, size, monkeypatch):
     """the counting form of the window build ([tag | H | L] words, one add per sighting) against the
     compare-and-swap form and the oracle: deep coverage (saturating counts), mixed qualities, three
@@ -55,11 +67,13 @@ def test_window_kernels_agree(k, bits, size, monkeypatch):
     om, ov = db.sorted_dump()
     assert (ov >> np.uint64(1)).max() == (1 << bits) - 1  # saturation is reached
     assert 0 < (ov & np.uint64(1)).sum() < ov.size        # both quality levels present
-    for kernel in ("count16", "count", "cas"):  # the default (16-bit counters where the bucket allows), generic counters, CAS
+    # the default (16-bit counters where tag and bucket allow; k = 31: wide tags, 10-bit counters), generic counters, CAS
+    for kernel in ("count16", "count", "cas"):
         monkeypatch.setenv("QH_WINDOW_KERNEL", kernel)
         h, st, m, v = build(data, k, bits, size, "partition", chunks=3)
         assert st["instances"] == n and st["distinct"] == om.size
         assert (m == om).all() and (v == ov).all(), kernel
+        assert_window_pass_is_live(h, "QH_WINDOW_KERNEL=" + kernel)
         h.close()
 
 
@@ -76,6 +90,7 @@ def test_partitioned_growth_and_contention():
     h, st, m, v = build(data, 21, 7, 1 << 14, "partition", chunks=2)
     assert st["instances"] == n and st["grows"] >= 2
     assert (m == om).all() and (v == ov).all()
+    assert_window_pass_is_live(h, "growth and contention")
 
 
 def test_partitioned_add_mers_and_sharded():

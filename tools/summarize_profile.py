@@ -42,12 +42,21 @@ for k, t in traffic.items():
     n = k.replace("void ", "")
     if n.startswith(("k_partition", "k_window", "k_build_direct", "k_index_text")):
         per[n] = t["fetch_bytes_x2"] + t["write_bytes"]
+# HBM bytes of ONE step (bench.py's roofline.traffic): every kernel of the build, launches per step from the trace
+whole = None
+if "k_index_text" in out and "FETCH_SIZE" in out["k_index_text"]:
+    steps = out["k_index_text"]["FETCH_SIZE"]["launches"]
+    whole = 0.0
+    for k, t in traffic.items():
+        n = k.replace("void ", "")
+        if n.startswith("k_") and not n.startswith(("k_random_access", "k_lds_rate")):
+            whole += (t["fetch_bytes_x2"] + t["write_bytes"]) * out[k]["FETCH_SIZE"]["launches"] / steps
 if per:
     old = {}
     if os.path.exists("profiles/pmc_traffic.json"):
         old = json.load(open("profiles/pmc_traffic.json")).get("per_kernel_hbm_bytes_per_launch", {})
     old.update(per)
-    json.dump({"per_kernel_hbm_bytes_per_launch": old,
+    json.dump({"per_kernel_hbm_bytes_per_launch": old, "whole_step_hbm_bytes": whole,
                "source": "%s/traffic.json (kernels absent from that run keep their earlier figure): (TCC FETCH_SIZE*2 + WRITE_SIZE) KiB "
                          "per launch, separate --pmc passes, gfx950 FETCH_SIZE x2 correction (MI355X_MICROARCH.md HBM section)" % dst},
               open("profiles/pmc_traffic.json", "w"), indent=1, sort_keys=True)
