@@ -8,8 +8,11 @@ A step = one complete database build over one batch of synthetic reads whose FAS
 text is already resident in HBM: table clear + FASTQ indexing + k-mer extraction +
 (N>1: all-to-all exchange) + insertion, until every k-mer is visible in the table.
 N=1 workload = BASELINE.json configs[1]: 5 Mbp genome, 2M x 100 bp reads, 1 % errors,
-k=24, -s 50M, -b 7, -q 38 (154 M insertions per step). N>1: weak scaling, the same
-2M reads per GPU drawn from an N x 5 Mbp genome, table -s N x 50M sharded by hash.
+k=24, -s 50M, -b 7, -q 38 (154 M insertions per step).
+N>1 workload = BASELINE.json configs[2]: 100 Mbp genome, 50 M x 100 bp reads IN ALL (3.85 G insertions
+per step), k=24, -s 2G hash-sharded over the N GPUs: strong scaling, every rank holds 50M / N reads in
+pieces of 2 M that flow through the extract / exchange / insert pipeline (quorum_amd/dist_build.py).
+`--workload c2` runs that workload on one GPU too (the matching N=1 point of the scaling curve).
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -26,7 +29,8 @@ import torch
 import torch.distributed as dist
 
 K, BITS, MIN_QUAL, READ_LEN = 24, 7, 38, 100
-GENOME_PER_GPU, READS_PER_GPU, SIZE_PER_GPU = 5_000_000, 2_000_000, 50_000_000
+GENOME_PER_GPU, READS_PER_GPU, SIZE_PER_GPU = 5_000_000, 2_000_000, 50_000_000                 # configs[1]
+C2_GENOME, C2_READS_TOTAL, C2_SIZE, C2_PIECE_READS = 100_000_000, 50_000_000, 2_000_000_000, 2_000_000  # configs[2]
 ALG_BYTES_PER_KMER = 16.0 + 2.0 * READ_LEN / (READ_LEN - K + 1)   # 18.6 B
 HBM_PEAK_GBS = 8000.0                                               # MI355X_MICROARCH.md: 8 TB/s
 
@@ -60,7 +64,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=READS_PER_GPU, help="reads per GPU (default: the named config)")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the named config)")
+    ap.add_argument("--workload", default="auto", choices=["auto", "c1", "c2"],
+                    help="auto: BASELINE configs[1] on one GPU, configs[2] (50 M reads in all) on several")
+    ap.add_argument("--piece-reads", type=int, default=0,
+                    help="configs[2]: reads per pipelined piece (default: so that a piece brings a shard about half as many "
+                         "k-mers as it has slots -- the window pass streams the whole shard once per piece -- but at least 2 M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="auto", choices=["auto", "direct", "partition"], help="build strategy (A/B runs)")
     ap.add_argument("--level1-bits", type=int, default=-1)
@@ -88,18 +97,44 @@ def main():
     from quorum_amd import synth
     from quorum_amd.dist_build import ShardedBuilder
 
-    genome = synth.make_genome(GENOME_PER_GPU * world, seed=42)
-    fq = synth.make_fastq(genome, args.reads, READ_LEN, err=0.01, n_rate=0.0005, seed=42, first_id=rank * args.reads)
-    chunk = torch.from_numpy(fq).to(dev)           # the FASTQ text, resident in HBM
+    workload = args.workload if args.workload != "auto" else ("c1" if world == 1 else "c2")
+    if workload == "c1":
+        reads_rank = args.reads or READS_PER_GPU
+        genome_bases, total_size = GENOME_PER_GPU * world, SIZE_PER_GPU * world
+        genome = synth.make_genome(genome_bases, seed=42)
+        fq = synth.make_fastq(genome, reads_rank, READ_LEN, err=0.01, n_rate=0.0005, seed=42, first_id=rank * reads_rank)
+        pieces = [torch.from_numpy(fq).to(dev)]          # the FASTQ text, resident in HBM
+        piece_reads = [reads_rank]
+    else:
+        # configs[2]: the reads are drawn on the GPU (50 M reads are too many to draw on the host in a benchmark run)
+        from quorum_amd import synth_gpu
+        reads_rank = args.reads or C2_READS_TOTAL // world
+        genome_bases, total_size = C2_GENOME, C2_SIZE
+        genome = synth_gpu.make_genome(genome_bases, dev, seed=42)
+        pieces, piece_reads, fq = [], [], None
+        if not args.piece_reads:
+            slots_rank = (1 << (C2_SIZE - 1).bit_length()) // world
+            want = max(C2_PIECE_READS, slots_rank // 2 // (READ_LEN - K + 1))
+            args.piece_reads = -(-reads_rank // max(1, round(reads_rank / want)))   # equal pieces
+        for p0 in range(0, reads_rank, args.piece_reads):
+            n = min(args.piece_reads, reads_rank - p0)
+            codes, qual, isN = synth_gpu.make_reads(genome, n, READ_LEN, seed=1000 * rank + len(pieces) + 1)
+            pieces.append(synth_gpu.fastq_text(codes, qual, isN, first_id=rank * reads_rank + p0))
+            piece_reads.append(n)
+            del codes, qual, isN
+        del genome
+        torch.cuda.empty_cache()
     torch.cuda.synchronize()
 
-    b = ShardedBuilder(K, BITS, SIZE_PER_GPU * world, MIN_QUAL, rank, world, local)
+    b = ShardedBuilder(K, BITS, total_size, MIN_QUAL, rank, world, local)
     b.h.set_mode(args.mode, args.level1_bits)
     b.h.enable_timing(True)
 
     def step():
         b.reset()
-        b.add_fastq_device(chunk, max_items=args.reads * (READ_LEN - K + 1))
+        for piece, n in zip(pieces, piece_reads):
+            b.add_fastq_device(piece, max_items=n * (READ_LEN - K + 1))
+        b.flush()
         b.h.sync()
 
     def fence():
@@ -141,15 +176,17 @@ def main():
                   "k_partition<0, false, 0>" if world == 1 else "k_partition<1, false, 0> (level 1)",
                   "k_partition<1, false, 0>" if world == 1 else "k_partition<1, false, 0> (level 2)",
                   "k_window_count<true>")  # the counting form with 16-bit counters at this geometry
-        per_launch = st["instances"]                # this rank's insertions per launch of each main kernel
         step_s = dt / args.steps
+        per_gpu_step = per_step / world             # insertions per GPU and step (the roofline is a per-GPU quantity)
+        launches_per_step = max(1.0, ktimes[3][1] / args.steps) if partitioned else 1.0   # one per piece of reads
+        per_launch = st["instances"] / launches_per_step   # this rank's insertions per launch of each main kernel
         # Headline roofline = the WHOLE STEP: SURVEY 8(d)'s 18.6 algorithmic bytes per k-mer (16 B of table traffic + the
         # read's text) over the step's wall time. No single kernel moves those bytes (level 1 never touches the table,
         # the window pass never sees the text), so pricing one kernel's time with them would flatter it.
-        achieved = per_launch * ALG_BYTES_PER_KMER / step_s / 1e9
+        achieved = per_gpu_step * ALG_BYTES_PER_KMER / step_s / 1e9
         # Each main kernel against the bytes IT must move per k-mer in this three-pass design:
         text_b = 2.0 * READ_LEN / (READ_LEN - K + 1)
-        slots_per_kmer = st["slots"] / max(1, per_launch)
+        slots_per_kmer = st["slots"] / max(1.0, per_launch)
         own_bytes = (None,                                  # slot 0: small preparation kernels (or the direct path)
                      text_b + 8.0,                          # level 1: the read's text in, one 8-byte item out
                      16.0,                                  # level 2: item in, item out
@@ -175,15 +212,21 @@ def main():
         out = {
             "metric": "k-mers/s into HQ-bit hash", "value": per_step * args.steps / dt, "unit": "k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "higher_is_better": True, "scaling": "weak" if workload == "c1" else "strong", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: synthetic %d Mbp genome, %d x %d bp reads per GPU, 1%% subst errors, "
-                                   "k=%d, -s %dM, -b %d, -q %d; FASTQ resident in HBM; step = clear + index + extract + %sinsert"
-                                   % (GENOME_PER_GPU * world // 1_000_000, args.reads, READ_LEN, K,
-                                      SIZE_PER_GPU * world // 1_000_000, BITS, MIN_QUAL,
-                                      "all-to-all exchange + " if world > 1 else ""),
+            "config": {"workload": ("BASELINE configs[1]: synthetic %d Mbp genome, %d x %d bp reads per GPU, 1%% subst errors, "
+                                    "k=%d, -s %dM, -b %d, -q %d; FASTQ resident in HBM; step = clear + index + extract + %sinsert"
+                                    % (genome_bases // 1_000_000, reads_rank, READ_LEN, K, total_size // 1_000_000, BITS, MIN_QUAL,
+                                       "all-to-all exchange + " if world > 1 else "")) if workload == "c1" else
+                                   ("BASELINE configs[2]: synthetic %d Mbp genome, %d x %d bp reads IN ALL (%d per GPU in pieces of "
+                                    "%d), 1%% subst errors, k=%d, -s %dM sharded by hash over %d GPU(s), -b %d, -q %d; FASTQ resident "
+                                    "in HBM; step = clear + per piece (index + extract by owner%s + insert), pieces pipelined"
+                                    % (genome_bases // 1_000_000, reads_rank * world, READ_LEN, reads_rank, args.piece_reads, K,
+                                       total_size // 1_000_000, world, BITS, MIN_QUAL,
+                                       " + all-to-all exchange" if world > 1 else "")),
                        "insertions_per_step": int(per_step), "distinct_per_gpu": int(st["distinct"]),
-                       "slots_per_gpu": int(st["slots"]), "parallelism": "hash-sharded x%d" % world},
+                       "slots_per_gpu": int(st["slots"]), "pieces_per_gpu": len(pieces),
+                       "bucket_overflow_retries": int(getattr(b, "retries", 0)), "parallelism": "hash-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "scope": "whole step (every kernel of one build): algorithmic bytes / step time",
@@ -191,8 +234,7 @@ def main():
                          "dominant_kernel": knames[dom], "kernel_avg_ms": avgs[dom], "kernel_launches": int(ktimes[dom][1]),
                          "kernels": per_kernel},
         }
-        kernel_avg_ms = avgs[dom]
-        if world == 1:
+        if world == 1 and workload == "c1":
             # measured random-access roofline: uniformly random 64-bit atomicCAS / load+CAS /
             # 8-byte loads over a table of this config's size, same number of updates as one step
             import ctypes as C
@@ -203,11 +245,15 @@ def main():
                 ms = C.c_double()
                 check(lib.qh_bench_random_access(local, lsize, int(per_launch), mode, 3, C.byref(ms)))
                 ra[name + "_per_s"] = per_launch / (ms.value * 1e-3)
-            ra["kernel_kmers_per_s"] = per_launch / (kernel_avg_ms * 1e-3) if kernel_avg_ms > 0 else 0.0
-            ra["frac_of_random_cas"] = ra["kernel_kmers_per_s"] / ra["cas_per_s"]
+            # not a roofline fraction: how the partitioned build's whole-step rate compares with what one global
+            # atomic per k-mer could reach at best
+            ra["step_kmers_per_s"] = out["value"]
+            ra["step_vs_random_cas"] = out["value"] / ra["cas_per_s"]
             out["random_access_roofline"] = ra
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(fq, args.reads)
+            if fq is None:
+                fq = pieces[0].cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(fq, piece_reads[0])
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

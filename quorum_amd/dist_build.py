@@ -180,46 +180,152 @@ def exchange_buckets(buckets, counts, group=None):
 
 
 class ShardedBuilder:
-    """Per-rank driver: extract+bucket the local chunk, exchange, insert what this shard owns."""
+    """Per-rank driver of the hash-sharded build: every piece of reads goes through three stages,
 
-    def __init__(self, k, bits, total_size, min_qual, rank, world, device, reprobe_limit=126, group=None):
+        extract + bucket by owner shard  ->  all-to-all exchange  ->  insert what this shard owns,
+
+    and the stages of consecutive pieces overlap: while piece i travels (RCCL's own stream), piece i+1 is
+    extracted (the extraction handle's stream) and piece i-1 is inserted (the shard handle's stream). Counts travel
+    ahead of the items in one small all-to-all. A piece whose buckets overflow (a skewed chunk) is extracted again
+    with twice the bucket capacity instead of failing.
+
+    All ranks must feed the same number of pieces (a rank that has run out of reads passes None); finish() /
+    flush() drain the pipeline."""
+
+    def __init__(self, k, bits, total_size, min_qual, rank, world, device, reprobe_limit=126, group=None,
+                 cap_factor=1.25):
         from .mer_database import HashWithQuality
+        self.cap_factor = cap_factor     # bucket capacity = mean share x this (tests lower it to force the retry)
         assert world & (world - 1) == 0, "number of shards must be a power of two"
         self.k, self.rank, self.world, self.group = k, rank, world, group
         self.shard_bits = int(math.log2(world))
         self.device = torch.device("cuda", device)
         self.h = HashWithQuality(total_size, 2 * k, bits, min_qual=min_qual, device=device,
                                  reprobe_limit=reprobe_limit, shard_bits=self.shard_bits, shard_id=rank)
-        self.h.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
-        self._buckets = None
+        self.hx = None           # extraction handle (its table is never used: smallest size)
+        self._ins_stream = None
+        if world > 1:
+            self.hx = HashWithQuality(1 << 13, 2 * k, bits, min_qual=min_qual, device=device,
+                                      reprobe_limit=reprobe_limit, shard_bits=self.shard_bits, shard_id=rank)
+            self._ins_stream = torch.cuda.Stream(self.device)
+            self.h.set_stream(self._ins_stream.cuda_stream)
+        else:
+            self.h.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self._buckets = [None, None]     # send side, two pieces in flight
         self._counts = torch.zeros(world, dtype=torch.int64, device=self.device)
+        self._recv = [None, None]        # receive side
+        self._sent_done = [None, None]   # event: the exchange that read _buckets[j] has completed
+        self._inflight = None            # (piece index, work handle or None, recv tensor, recv count)
+        self._npieces = 0
+        self.retries = 0                 # bucket overflows that were resolved by a larger capacity
 
-    def _ensure(self, cap):
-        if self._buckets is None or self._buckets.shape[1] < cap:
-            self._buckets = torch.empty((self.world, cap), dtype=torch.int64, device=self.device)
-
-    def add_fastq_device(self, chunk, max_items=None):
-        """chunk: 1-D uint8 CUDA tensor holding strict 4-line FASTQ records"""
-        from ._lib import lib, check
+    # ---- stage 1
+    def _extract(self, chunk, max_items, slot):
+        """-> per-destination counts; the items lie in self._buckets[slot]"""
+        from ._lib import lib, check, QhError, QH_EBADARG, last_error
+        if chunk is None or chunk.numel() == 0:
+            return [0] * self.world
         nbytes = chunk.numel()
         if max_items is None:
             max_items = nbytes // 2
+        cap = int(max_items / self.world * self.cap_factor) + 4096
+        while True:
+            b = self._buckets[slot]
+            if b is None or b.shape[1] < cap:
+                b = self._buckets[slot] = torch.empty((self.world, cap), dtype=torch.int64, device=self.device)
+                torch.cuda.current_stream(self.device).synchronize()
+            st = lib.qh_build_extract_partitioned_device(self.hx._h, C.c_void_p(chunk.data_ptr()), nbytes,
+                                                         C.c_void_p(b.data_ptr()), b.shape[1],
+                                                         C.c_void_p(self._counts.data_ptr()))
+            if st == QH_EBADARG and "cap_per_shard too small" in last_error():
+                cap = 2 * b.shape[1]        # a skewed piece: again with room to spare
+                self.retries += 1
+                continue
+            check(st)
+            return self._counts.tolist()
+
+    # ---- stage 2
+    def _start_exchange(self, slot, counts):
+        """counts ahead, then the items; returns (work or None, recv tensor, number received)"""
+        world, dev = self.world, self.device
+        staged = dist.get_backend(self.group) != "nccl"     # rehearsal (several ranks on one GPU over gloo): through the host
+        cdev = torch.device("cpu") if staged else dev
+        sc = torch.tensor(counts, dtype=torch.int64, device=cdev)
+        rc = torch.empty(world, dtype=torch.int64, device=cdev)
+        dist.all_to_all_single(rc, sc, group=self.group)
+        recv_counts = rc.tolist()
+        n = int(sum(recv_counts))
+        r = self._recv[slot]
+        if r is None or r.numel() < n:
+            r = self._recv[slot] = torch.empty(max(n + n // 8, 1), dtype=torch.int64, device=dev)
+        b = self._buckets[slot]
+        if b is None:                  # this rank had nothing to extract yet
+            b = self._buckets[slot] = torch.empty((world, 1), dtype=torch.int64, device=dev)
+        send = [b[s, :counts[s]] for s in range(world)]
+        if staged:   # gloo has no list form: one packed buffer
+            got = torch.empty(n, dtype=torch.int64)
+            dist.all_to_all_single(got, torch.cat([x.cpu() for x in send]), output_split_sizes=recv_counts,
+                                   input_split_sizes=list(counts), group=self.group)
+            r[:n].copy_(got)
+            torch.cuda.current_stream(dev).synchronize()
+            return None, r, n
+        global _LIST_ALL_TO_ALL_OK
+        if _LIST_ALL_TO_ALL_OK:
+            try:   # the bucket rows are sent where they lie
+                work = dist.all_to_all(list(r[:n].split(recv_counts)), send, group=self.group, async_op=True)
+                return work, r, n
+            except (RuntimeError, NotImplementedError):
+                _LIST_ALL_TO_ALL_OK = False   # every rank fails alike (same torch build): fall back together
+        packed = torch.cat(send)
+        work = dist.all_to_all_single(r[:n], packed, output_split_sizes=recv_counts, input_split_sizes=list(counts),
+                                      group=self.group, async_op=True)
+        self._packed = packed                 # alive until the exchange has completed
+        return work, r, n
+
+    # ---- stage 3
+    def _insert(self, slot, work, recv, n):
+        if work is not None:
+            with torch.cuda.stream(self._ins_stream):
+                work.wait()                       # the shard handle's stream waits for the items; the host does not
+                ev = torch.cuda.Event()
+                ev.record(self._ins_stream)
+            self._sent_done[slot] = ev
+        if n:
+            self.h.add_hashed_device(recv.data_ptr(), n)   # waits (host) for the previous piece's insert, then enqueues
+        else:
+            self.h.sync()                                  # same guarantee for the buffers when nothing arrived
+
+    def add_fastq_device(self, chunk, max_items=None):
+        """chunk: 1-D uint8 CUDA tensor holding strict 4-line FASTQ records (None: this rank has no more reads but
+        other ranks may). The chunk must stay alive until the next call returns."""
         if self.world == 1:
-            self.h.add_fastq_device(chunk.data_ptr(), nbytes)
+            if chunk is not None and chunk.numel():
+                self.h.add_fastq_device(chunk.data_ptr(), chunk.numel())
             return
-        cap = int(max_items / self.world * 1.25) + 4096
-        self._ensure(cap)
-        check(lib.qh_build_extract_partitioned_device(self.h._h, C.c_void_p(chunk.data_ptr()), nbytes,
-                                                      C.c_void_p(self._buckets.data_ptr()), self._buckets.shape[1],
-                                                      C.c_void_p(self._counts.data_ptr())))
-        counts = self._counts.tolist()
-        recv, _ = exchange_buckets(self._buckets, counts, self.group)
-        if recv.numel():
-            self.h.add_hashed_device(recv.data_ptr(), recv.numel())
-            self.h.sync()  # recv must stay alive until the insert kernel has consumed it
+        i = self._npieces
+        slot = i & 1
+        if self._sent_done[slot] is not None:     # the exchange that read this send buffer two pieces ago
+            self._sent_done[slot].synchronize()
+            self._sent_done[slot] = None
+        counts = self._extract(chunk, max_items, slot)       # overlaps piece i-1 on the wire and piece i-2 being inserted
+        prev = self._inflight
+        self._inflight = None
+        if prev is not None:
+            self._insert(*prev)                              # piece i-1: its items have been requested a stage ago
+        work, recv, n = self._start_exchange(slot, counts)
+        self._inflight = (slot, work, recv, n)
+        self._npieces += 1
+
+    def flush(self):
+        """drains the pipeline: every piece fed so far is in the table (or queued on the shard handle's stream)"""
+        prev, self._inflight = self._inflight, None
+        if prev is not None:
+            self._insert(*prev)
 
     def reset(self):
+        self.flush()
         self.h.reset()
 
     def finish(self):
+        self.flush()
         return self.h.done()

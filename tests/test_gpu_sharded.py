@@ -79,21 +79,90 @@ def test_sharded_build_single_process(shard_bits, tmp_path):
 
 
 def test_two_rank_bench_rehearsal():
-    """bench.py's N>1 path end to end (extract+bucket by owner, all-to-all, insert) with two ranks
-    sharing the one GPU and gloo standing in for RCCL; also checks the sharded result."""
+    """bench.py's N>1 path end to end (BASELINE configs[2] shape: reads drawn on the GPU, pieces through the
+    extract / exchange / insert pipeline) with two ranks sharing the one GPU and gloo standing in for RCCL."""
     import json
     import os
     import subprocess
     import sys
+    import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
     env = dict(os.environ, QH_DIST_BACKEND="gloo", QH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29571", os.path.join(root, "bench.py"),
-                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "200000"],
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "200000", "--piece-reads", "70000"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong" and "configs[2]" in d["config"]["workload"]
     # 2 ranks x 200k reads x (100-24+1) windows, minus the windows that contain an N
     assert 0.97 * 2 * 200000 * 77 < d["config"]["insertions_per_step"] <= 2 * 200000 * 77
+    assert d["config"]["pieces_per_gpu"] == 3
+
+
+def _pipeline_rank(rank, world, port, outdir):
+    """one rank of the pipelined sharded build: gloo between the ranks, both on GPU 0"""
+    import os
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch_model as tm
+    from quorum_amd.dist_build import ShardedBuilder
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        k, bits, thresh, L = 24, 7, 38, 100
+        genome = tm.make_genome(300_000, "cuda:0")
+        # rank 0 feeds three pieces, rank 1 two and then None; the small bucket capacity forces the overflow retry
+        b = ShardedBuilder(k, bits, 1 << 23, thresh, rank, world, 0, cap_factor=0.4)
+        n_pieces = 3 if rank == 0 else 2
+        canon, hq = [], []
+        for i in range(3):
+            if i < n_pieces:
+                codes, qual, isN = tm.make_reads(genome, 30_000 + 5_000 * i, L, seed=10 * rank + i, tails=True)
+                chunk = tm.fastq_text(codes, qual, isN)
+                c, q = tm.model_items(codes, qual, isN, k, thresh)
+                canon.append(c.cpu())
+                hq.append(q.cpu())
+                torch.cuda.synchronize()
+                b.add_fastq_device(chunk)
+            else:
+                b.add_fastq_device(None)
+        st = b.finish()
+        m, v = b.h.dump()
+        np.savez(os.path.join(outdir, "rank%d.npz" % rank), m=m, v=v, canon=torch.cat(canon).numpy(), hq=torch.cat(hq).numpy(),
+                 inst=np.array([st["instances"]]), retries=np.array([b.retries]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_sharded_builder_two_ranks(tmp_path):
+    """ShardedBuilder's extract / exchange / insert pipeline with two ranks (gloo, sharing the GPU): uneven numbers of
+    pieces, bucket overflow resolved by the retry, union of the shards == the model of all reads"""
+    import socket
+    import torch.multiprocessing as mp
+    import torch_model as tm
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    mp.start_processes(_pipeline_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r = [np.load(str(tmp_path / ("rank%d.npz" % i))) for i in range(2)]
+    canon = torch.from_numpy(np.concatenate([x["canon"] for x in r]))
+    hq = torch.from_numpy(np.concatenate([x["hq"] for x in r]))
+    mm, mv = tm.model_table(canon, hq, 7)
+    assert sum(int(x["inst"][0]) for x in r) == canon.numel()
+    assert all(int(x["retries"][0]) >= 1 for x in r)
+    m = np.concatenate([x["m"] for x in r])
+    v = np.concatenate([x["v"] for x in r])
+    assert np.unique(m).size == m.size
+    sm, sv = sorted_pairs(m, v)
+    assert (sm == mm.numpy().view(np.uint64)).all() and (sv == mv.numpy().view(np.uint64)).all()
+    assert (owner_np(r[0]["m"], 24, 1) == 0).all() and (owner_np(r[1]["m"], 24, 1) == 1).all()
