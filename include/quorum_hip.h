@@ -202,6 +202,35 @@ int qh_build_extract_partitioned_device(qh_build* h, const void* dev_buf, size_t
                                         uint64_t* dev_out, uint64_t cap_per_shard,
                                         uint64_t* dev_counts);
 
+/* ------------------------------------------------- several GPUs, one process */
+
+/* The hash-sharded build across n_devices GPUs of one node driven from ONE host process: the multi-GPU form of
+ * hash_with_quality + quality_mer_counter (src/create_database.cc:117-123 is one process with -t threads; here one host
+ * thread per GPU). `size` is the TOTAL table size; shard d (owner = low log2(n) bits of the position hash) lives on
+ * devices[d] (NULL: devices 0..n-1; the same device may be named more than once). n_devices must be a power of two.
+ * The k-mers of every chunk are exchanged all-to-all: RCCL (grouped ncclSend/ncclRecv over xGMI, librccl loaded at run
+ * time) between distinct devices, plain peer copies otherwise or with QH_MULTI_TRANSPORT=copy. */
+typedef struct qh_multi qh_multi;
+int qh_multi_create(qh_multi** out, int k, int bits, uint64_t size, int min_qual, int reprobe_limit,
+                    int n_devices, const int* devices);
+void qh_multi_destroy(qh_multi* m);
+/* quality_mer_counter::start (src/create_database.cc:56-95) over one host buffer of FASTQ text. The leading whole groups
+ * of 4 lines are cut into n parts at record boundaries, GPU d extracts part d bucketed by owner, the buckets are
+ * exchanged and every GPU inserts what it owns (the insert overlaps the next call's extraction). *consumed receives the
+ * bytes taken (a partial tail is left for the next call unless final_chunk). Text the GPU indexer rejects (multi-line
+ * records) is parsed by the sequential host parser on every shard instead, from then on (Jellyfish's FASTQ rules). */
+int qh_multi_add_fastq(qh_multi* m, const char* buf, size_t len, int final_chunk, size_t* consumed);
+/* hash_with_quality::done: waits for all shards; `total` sums their statistics (slots = all shards). */
+int qh_multi_finish(qh_multi* m, qh_build_stats* total);
+/* hash_with_quality::write (src/mer_database.hpp:115-126): equalises the shard sizes and serialises them into one file. */
+int qh_multi_write(qh_multi* m, const char* path, int argc, const char* const* argv);
+/* Content export of all shards (as qh_build_dump). */
+int qh_multi_dump(qh_multi* m, uint64_t* mers, uint64_t* vals, uint64_t cap, uint64_t* n);
+/* What the handle is doing: number of shards, 1 if the exchange runs over RCCL, chunks processed, parts that fell back to
+ * the host parser, bucket overflows resolved by a retry. Any pointer may be NULL. */
+int qh_multi_info(const qh_multi* m, int* n_devices, int* uses_rccl, uint64_t* rounds, uint64_t* fallback_parts,
+                  uint64_t* retries);
+
 /* -------------------------------------------------------------- query side */
 
 /* database_header fields (src/mer_database.hpp:43-63 + jellyfish::file_header) of

@@ -83,6 +83,13 @@ SIGNATURES = [
     ("qh_build_dump", C.c_int, [_p, _u64p, _u64p, C.c_uint64, _u64p]),
     ("qh_build_as_query", C.c_int, [_p, C.POINTER(_p)]),
     ("qh_build_extract_partitioned_device", C.c_int, [_p, _p, C.c_size_t, _p, C.c_uint64, _p]),
+    ("qh_multi_create", C.c_int, [C.POINTER(_p), C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, _i32p]),
+    ("qh_multi_destroy", None, [_p]),
+    ("qh_multi_add_fastq", C.c_int, [_p, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_size_t)]),
+    ("qh_multi_finish", C.c_int, [_p, C.POINTER(QhBuildStats)]),
+    ("qh_multi_write", C.c_int, [_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p)]),
+    ("qh_multi_dump", C.c_int, [_p, _u64p, _u64p, C.c_uint64, _u64p]),
+    ("qh_multi_info", C.c_int, [_p, C.POINTER(C.c_int), C.POINTER(C.c_int), _u64p, _u64p, _u64p]),
     ("qh_db_header_info", C.c_int, [C.c_char_p, C.POINTER(QhDbInfo)]),
     ("qh_query_open", C.c_int, [C.POINTER(_p), C.c_char_p, C.c_int]),
     ("qh_query_close", None, [_p]),

@@ -6,8 +6,9 @@
 // required), -m/--mer, -b/--bits (required), -q/--min-qual-value,
 // -Q/--min-qual-char (conflict), -t/--threads (=1), -o/--output
 // (="combined_database"), -p/--reprobe (=126), reads... (at least 1).
-// Not in upstream: --gpu N selects the HIP device; -t is accepted and ignored
-// (the GPU supplies the parallelism).
+// Not in upstream: --gpu N selects the HIP device; --gpus N builds the table hash-sharded over devices 0..N-1 (N a power
+// of two; --devices a,b,... names them) in this one process and serialises the shards into the one output file; -t is
+// accepted and ignored (the GPUs supply the parallelism).
 #include <errno.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -41,6 +42,8 @@ static const char* kHelp =
     " -o, --output=path                        Output file (combined_database)\n"
     " -p, --reprobe=int32                      Maximum number of reprobes (126)\n"
     "     --gpu=int                            HIP device to build on (0)\n"
+    "     --gpus=int                           Build hash-sharded over this many GPUs (1)\n"
+    "     --devices=list                       The HIP devices of the shards, comma separated\n"
     " -U, --usage                              Usage\n"
     " -h, --help                               This message\n"
     " -V, --version                            Version";
@@ -86,6 +89,8 @@ struct args_t {
   const char* output = "combined_database";
   int32_t reprobe = 126;
   int gpu = 0;
+  int gpus = 1;
+  std::vector<int> devices;
   std::vector<const char*> reads;
 };
 
@@ -93,7 +98,7 @@ static void parse(int argc, char** argv, args_t& a) {
   struct opt { char s; const char* l; };
   static const opt opts[] = {{'s', "size"}, {'m', "mer"}, {'b', "bits"}, {'q', "min-qual-value"},
                              {'Q', "min-qual-char"}, {'t', "threads"}, {'o', "output"}, {'p', "reprobe"},
-                             {'G', "gpu"}};
+                             {'G', "gpu"}, {'N', "gpus"}, {'D', "devices"}};
   bool only_pos = false;
   for (int i = 1; i < argc; ++i) {
     const char* s = argv[i];
@@ -111,7 +116,7 @@ static void parse(int argc, char** argv, args_t& a) {
       if (!key) error(std::string("unrecognized option '") + s + "'");
       val = eq ? eq + 1 : nullptr;
     } else {
-      for (auto& o : opts) if (s[1] == o.s && o.s != 'G') key = o.s;
+      for (auto& o : opts) if (s[1] == o.s && o.s != 'G' && o.s != 'N' && o.s != 'D') key = o.s;
       if (!key) error(std::string("invalid option -- '") + s[1] + "'");
       val = s[2] ? s + 2 : nullptr;
     }
@@ -133,6 +138,16 @@ static void parse(int argc, char** argv, args_t& a) {
         a.reprobe = (int32_t)v; break;
       }
       case 'G': a.gpu = (int)conv_uint(val, false, "int", 1024); break;
+      case 'N': a.gpus = (int)conv_uint(val, false, "int", 256); break;
+      case 'D': {
+        a.devices.clear();
+        std::string item;
+        for (const char* c = val;; ++c) {
+          if (*c == ',' || *c == 0) { a.devices.push_back((int)conv_uint(item.c_str(), false, "int", 1024)); item.clear(); if (!*c) break; }
+          else item.push_back(*c);
+        }
+        break;
+      }
     }
   }
   if (!a.size_given) error("[-s, --size=uint64] required switch");
@@ -141,6 +156,8 @@ static void parse(int argc, char** argv, args_t& a) {
   if (a.min_qual_value_given && a.min_qual_char_given)
     error("Switches [-Q, --min-qual-char=string] and [-q, --min-qual-value=uint32] are mutually exclusive");
   if (a.reads.empty()) error("Requires at least 1 argument.");
+  if (!a.devices.empty()) a.gpus = (int)a.devices.size();
+  if (a.gpus < 1 || (a.gpus & (a.gpus - 1))) error("The number of GPUs must be a power of two");
 }
 
 [[noreturn]] static void die(const char* what, int rc) {
@@ -263,6 +280,41 @@ static void feed_file(qh_build* h, const char* path, size_t chunk_bytes) {
   if (fd != 0) close(fd);
 }
 
+// The same for the sharded build: the chunk is handed to qh_multi_add_fastq, which cuts it into one part per GPU.
+static void feed_file_multi(qh_multi* m, const char* path, size_t chunk_bytes) {
+  const int fd = !strcmp(path, "-") ? 0 : open(path, O_RDONLY);
+  if (fd < 0) { fprintf(stderr, "Can't open file '%s'\n", path); exit(EXIT_FAILURE); }
+  struct stat st;
+  const bool regular = fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
+  if (regular && (size_t)st.st_size + 16 < chunk_bytes) chunk_bytes = (size_t)st.st_size + 16;
+  off_t pos = 0;
+  chunk_buf buf;
+  buf.reserve(chunk_bytes);
+  size_t have = 0;
+  bool eof = false, any = false;
+  while (!eof || have) {
+    if (!eof && have < buf.cap) {
+      const size_t want = buf.cap - have, r = read_some(fd, regular, &pos, buf.p + have, want);
+      have += r;
+      if (r < want) eof = true;
+    }
+    if (have == 0) break;
+    if (!any && buf.p[0] != '@') {
+      fprintf(stderr, "Unsupported format in file '%s' (create_database needs FASTQ: it reads a quality for every base)\n", path);
+      exit(EXIT_FAILURE);
+    }
+    any = true;
+    size_t used = 0;
+    const int rc = qh_multi_add_fastq(m, buf.p, have, eof, &used);
+    if (rc != QH_OK) die("create_database", rc);
+    if (used == 0 && !eof && have == buf.cap) buf.reserve(buf.cap * 2);  // a record longer than the chunk
+    memmove(buf.p, buf.p + used, have - used);
+    have -= used;
+    if (eof && used == 0 && have) { fprintf(stderr, "Truncated fastq file '%s'\n", path); exit(EXIT_FAILURE); }
+  }
+  if (fd != 0) close(fd);
+}
+
 int main(int argc, char* argv[]) {
   args_t args;
   parse(argc, argv, args);
@@ -281,12 +333,37 @@ int main(int argc, char* argv[]) {
 
   const auto t_start = std::chrono::steady_clock::now();
   auto secs = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
+  const char* cb = getenv("QUORUM_HIP_CHUNK_MB");
+  size_t chunk = (cb && atol(cb) > 0 ? (size_t)atol(cb) : 256) << 20;
+  if (args.gpus > 1) {  // the table hash-sharded over several GPUs, one process (src/create_database.cc:117-125)
+    qh_multi* m = nullptr;
+    int mrc = qh_multi_create(&m, (int)args.mer, (int)args.bits, args.size, (int)qual_thresh, args.reprobe, args.gpus,
+                              args.devices.empty() ? nullptr : args.devices.data());
+    if (mrc != QH_OK) error(qh_last_error());
+    const double t_init = secs();
+    for (const char* path : args.reads) feed_file_multi(m, path, chunk * (size_t)args.gpus);
+    qh_build_stats st;
+    if ((mrc = qh_multi_finish(m, &st)) != QH_OK) die("create_database", mrc);
+    const double t_feed = secs();
+    if ((mrc = qh_multi_write(m, args.output, argc, argv)) != QH_OK) die("create_database", mrc);
+    if (getenv("QUORUM_HIP_VERBOSE")) {
+      int uses_rccl = 0;
+      uint64_t rounds = 0, fb = 0, retries = 0;
+      qh_multi_info(m, nullptr, &uses_rccl, &rounds, &fb, &retries);
+      fprintf(stderr, "seconds: devices+tables %.3f  read+build %.3f  write %.3f\n", t_init, t_feed - t_init, secs() - t_feed);
+      fprintf(stderr, "gpus %d  exchange %s  rounds %llu  host-parsed chunks %llu  bucket retries %llu\n", args.gpus,
+              uses_rccl ? "rccl" : "peer copies", (unsigned long long)rounds, (unsigned long long)fb, (unsigned long long)retries);
+      fprintf(stderr, "reads %llu  k-mers %llu  high-quality %llu  distinct %llu  slots %llu  doublings %llu\n",
+              (unsigned long long)st.records, (unsigned long long)st.instances, (unsigned long long)st.hq_instances,
+              (unsigned long long)st.distinct, (unsigned long long)st.slots, (unsigned long long)st.grows);
+    }
+    qh_multi_destroy(m);
+    return 0;
+  }
   qh_build* h = nullptr;
   int rc = qh_build_create(&h, (int)args.mer, (int)args.bits, args.size, (int)qual_thresh, args.reprobe, args.gpu, 0, 0);
   if (rc != QH_OK) error(qh_last_error());
 
-  const char* cb = getenv("QUORUM_HIP_CHUNK_MB");
-  size_t chunk = (cb && atol(cb) > 0 ? (size_t)atol(cb) : 256) << 20;
   const double t_init = secs();
   for (const char* path : args.reads) feed_file(h, path, chunk);
 

@@ -64,6 +64,41 @@ def test_create_database_cli_end_to_end(tmp_path):
     q.close()
 
 
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0"])
+def test_create_database_cli_sharded_one_process(tmp_path, devices):
+    """quorum_create_database --devices a,b,...: the hash-sharded build from ONE process (qh_multi_*: a host thread per
+    shard, owner-bucketed extraction, all-to-all by peer copies, shards serialised into one file). The one-GPU box names
+    device 0 for every shard; with distinct devices the same code exchanges over RCCL. First file strict 4-line FASTQ in
+    many small rounds, second file multi-line (the host-parser route on every shard)."""
+    k, bits = 24, 7
+    g = synth.make_genome(100000)
+    fq1 = synth.make_fastq(g, 30000, 100, tails=True).tobytes()
+    fq2 = synth.make_fastq(g, 6000, 150, err=0.03, first_id=30000).tobytes()
+    recs = fq2.split(b"\n")
+    multi = []
+    for i in range(0, len(recs) - 1, 4):
+        s, q = recs[i + 1], recs[i + 3]
+        multi += [recs[i], s[:70], s[70:], b"+", q[:70], q[70:]]
+    (tmp_path / "a.fastq").write_bytes(fq1)
+    (tmp_path / "b.fastq").write_bytes(b"\n".join(multi) + b"\n")
+    out = str(tmp_path / "db.jf")
+    env = dict(os.environ, QUORUM_HIP_CHUNK_MB="1", QUORUM_HIP_VERBOSE="1")
+    r = subprocess.run([os.path.join(BIN, "quorum_create_database"), "-s", "400k", "-m", str(k), "-b", str(bits),
+                        "-q", "38", "--devices", devices, "-o", out, str(tmp_path / "a.fastq"), str(tmp_path / "b.fastq")],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    db = po.OracleDB(1 << 23, k, bits)
+    n = db.add_fastq(fq1, 38, threads=8) + db.add_fastq(fq2, 38, threads=8)
+    assert ("k-mers %d " % n) in r.stderr and ("reads %d " % 36000) in r.stderr
+    assert "exchange peer copies" in r.stderr and "host-parsed chunks 0" not in r.stderr
+    om, ov = db.sorted_dump()
+    q = qa.DatabaseQuery(out)
+    m, v = sorted_pairs(*q.dump())
+    assert m.size == om.size and (m == om).all() and (v == ov).all()
+    assert (q.lookup(om[::11]) == ov[::11]).all()
+    q.close()
+
+
 def test_cli_min_qual_char_and_missing_file(tmp_path):
     fq = b"@a\nACGTACGTAC\n+\nIIII#IIIII\n"
     (tmp_path / "r.fq").write_bytes(fq)
