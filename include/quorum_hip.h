@@ -15,8 +15,11 @@
  *
  * Threading: a build handle is driven by one host thread at a time (the GPU
  * supplies the parallelism that upstream gets from -t threads).  A query handle
- * is immutable after open; concurrent calls on one handle serialise on an
- * internal mutex (each call owns the handle's staging buffers).
+ * is immutable after open; its batched lookups may be called concurrently from
+ * many host threads, like the const methods of database_query: every call runs
+ * on a stream and staging buffers of its own (up to 16 at a time, further
+ * callers wait for one).  The table reductions (stats, histogram, dump)
+ * serialise on a mutex.
  */
 #ifndef QUORUM_HIP_H
 #define QUORUM_HIP_H
@@ -150,7 +153,11 @@ int qh_build_write(qh_build* h, const char* path, int argc, const char* const* a
 /* Sharded serialisation: every shard pwrite()s its slice of the keys and vals
  * images into one file. The shard called with write_header != 0 must run first
  * (it creates the file and sizes it); all shards must have the same table size
- * (see qh_build_grow_to). No upstream counterpart (upstream is one process). */
+ * (see qh_build_grow_to). The calls of different shards must be SERIALISED (one
+ * writer at a time, a barrier between ranks in a multi-process build): when the
+ * bits+1-wide value fields do not pack evenly into 64-bit words (-b 2, 4, 6 ...),
+ * neighbouring shards share a boundary word of the values image, which each
+ * writer completes by read-OR-write. No upstream counterpart (one process). */
 int qh_build_write_shard(qh_build* h, const char* path, int argc, const char* const* argv,
                          int write_header);
 
@@ -250,6 +257,9 @@ typedef struct qh_db_info {
   char format[32];
 } qh_db_info;
 int qh_db_header_info(const char* path, qh_db_info* info);
+/* The same from the first bytes of a database held in memory: file_header::read(std::istream&) as
+ * database_header uses it (src/mer_database.hpp:257-267). `len` must cover the 9-digit length prefix and the header. */
+int qh_db_header_parse(const void* data, size_t len, qh_db_info* info);
 
 /* database_query::database_query(filename, no_mmap) (src/mer_database.hpp:270-278):
  * parses the header and loads the table into HBM of `device`. */

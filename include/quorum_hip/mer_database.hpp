@@ -6,13 +6,26 @@
 // Same names, argument meaning and error behaviour as upstream: add() returns false when the
 // table is full and cannot grow, every thread calls done(), open/parse failures throw
 // std::runtime_error. add() may be called concurrently (calls are batched under a mutex and
-// handed to the GPU a million at a time); the const methods of database_query are thread-safe.
+// handed to the GPU a million at a time); the const methods of database_query are thread-safe and run
+// concurrently (the library gives every call a stream of its own).
+//
+// One difference in WHEN a full table shows: upstream's add() returns false on the very call that cannot
+// be placed (src/mer_database.hpp:97-99). Here a batch of up to 2^20 adds is placed at once, so add()
+// returns false from the call that flushes the failing batch (and from every call after it), and a
+// failure in the last, partial batch surfaces in done(), which then throws std::runtime_error("Hash is
+// full") -- the exception create_database.cc:86-87 throws when add() fails -- so that a caller ported
+// from upstream cannot miss it. write() flushes too and throws the same.
 #ifndef QUORUM_HIP_MER_DATABASE_HPP
 #define QUORUM_HIP_MER_DATABASE_HPP
 
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
+#include <istream>
 #include <iterator>
+#include <ostream>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -92,6 +105,21 @@ class database_header {
 public:
   database_header() { memset(&info_, 0, sizeof info_); }
   bool read(const char* path) { return qh_db_header_info(path, &info_) == QH_OK || info_.size != 0; }
+  // bool read(std::istream&) (jellyfish::file_header::read as src/mer_database.hpp:261 calls it): parses the header
+  // and leaves the stream at offset(), where the keys image starts
+  bool read(std::istream& is) {
+    char pre[9];
+    if (!is.read(pre, 9)) return false;
+    size_t hlen = 0;
+    for (int i = 0; i < 9; ++i) {
+      if (pre[i] < '0' || pre[i] > '9') return false;
+      hlen = hlen * 10 + (size_t)(pre[i] - '0');
+    }
+    std::string buf(pre, 9);
+    buf.resize(9 + hlen);
+    if (hlen && !is.read(&buf[9], (std::streamsize)hlen)) return false;
+    return qh_db_header_parse(buf.data(), buf.size(), &info_) == QH_OK || info_.size != 0;
+  }
   uint32_t bits() const { return info_.bits; }
   size_t value_bytes() const { return info_.value_bytes; }
   size_t key_bytes() const { return info_.key_bytes; }
@@ -143,18 +171,44 @@ public:
     quals_.push_back(quality ? 1 : 0);
     return mers_.size() < batch || flush_locked();
   }
-  // void done() (:128): every inserting thread calls it once
+  // void done() (:128): every inserting thread calls it once. Places what is still batched; a table that cannot
+  // take it throws (see the top of this file)
   void done() {
     std::lock_guard<std::mutex> lock(mu_);
-    flush_locked();
+    if (!flush_locked()) throw std::runtime_error("Hash is full");
   }
-  // void write(std::ostream&, database_header*) (:115); the C ABI writes by path
+  // the C ABI writes by path
   void write(const char* path, int argc = 0, const char* const* argv = 0) {
     {
       std::lock_guard<std::mutex> lock(mu_);
-      flush_locked();
+      if (!flush_locked()) throw std::runtime_error("Hash is full");
     }
     if (qh_build_write(h_, path, argc, argv) != QH_OK) throw std::runtime_error(qh_last_error());
+  }
+  // void write(std::ostream& os, database_header* header = 0) const (:115-126): header, keys image, values image.
+  // The library serialises to a file (the table is copied out of HBM in pieces), so the stream form goes through a
+  // temporary file in $TMPDIR; *header receives the fields of what was written (bits, key_bytes, value_bytes, offset...).
+  void write(std::ostream& os, database_header* header = 0) {
+    const char* dir = getenv("TMPDIR");
+    std::string tmp = std::string(dir && *dir ? dir : "/tmp") + "/quorum_hip_db_XXXXXX";
+    const int fd = mkstemp(&tmp[0]);
+    if (fd < 0) throw std::runtime_error("Failed to create a temporary file for the database image");
+    close(fd);
+    try {
+      write(tmp.c_str());
+      if (header && !header->read(tmp.c_str())) throw std::runtime_error("Can't parse the header just written");
+      FILE* f = fopen(tmp.c_str(), "rb");
+      if (!f) throw std::runtime_error("Can't reopen the temporary database image");
+      std::vector<char> buf(1 << 22);
+      size_t got;
+      while ((got = fread(buf.data(), 1, buf.size(), f)) > 0) os.write(buf.data(), (std::streamsize)got);
+      fclose(f);
+    } catch (...) {
+      unlink(tmp.c_str());
+      throw;
+    }
+    unlink(tmp.c_str());
+    if (!os) throw std::runtime_error("Failed to write the database to the stream");
   }
   qh_build* handle() { return h_; }
 };

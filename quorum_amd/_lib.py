@@ -91,6 +91,7 @@ SIGNATURES = [
     ("qh_multi_dump", C.c_int, [_p, _u64p, _u64p, C.c_uint64, _u64p]),
     ("qh_multi_info", C.c_int, [_p, C.POINTER(C.c_int), C.POINTER(C.c_int), _u64p, _u64p, _u64p]),
     ("qh_db_header_info", C.c_int, [C.c_char_p, C.POINTER(QhDbInfo)]),
+    ("qh_db_header_parse", C.c_int, [_p, C.c_size_t, C.POINTER(QhDbInfo)]),
     ("qh_query_open", C.c_int, [C.POINTER(_p), C.c_char_p, C.c_int]),
     ("qh_query_close", None, [_p]),
     ("qh_query_info", C.c_int, [_p, C.POINTER(C.c_int), C.POINTER(C.c_int), _u64p]),

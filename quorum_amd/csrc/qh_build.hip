@@ -110,9 +110,13 @@ bool qh_make_geom(int k, int bits, uint64_t size, int min_qual, int reprobe_limi
   g.vmask = qh_low_mask(g.vbits);
   g.max_val = ~0ull >> (64 - bits);  // mer_database.hpp:83
   if (g.vbits + g.pbits + g.rbits > 64) {
+    // upstream keeps the values in an array of their own and takes -b up to 63 (create_database.cc:111-112); here key,
+    // probe and value share one 64-bit word: name the largest -b this -m / -s / -p leaves room for
+    const int room = 64 - g.rbits - g.pbits - 1;
     snprintf(m, sizeof m,
-             "unsupported geometry: %d remainder + %d probe + %d value bits exceed one 64-bit slot "
-             "(use a larger -s, a smaller -b or a smaller -p)", g.rbits, g.pbits, g.vbits);
+             "unsupported geometry: %d remainder + %d probe + %d value bits exceed one 64-bit slot: with -m %d, this -s and "
+             "-p %d the largest -b is %d (a larger -s or a smaller -p leaves more)", g.rbits, g.pbits, g.vbits, k,
+             reprobe_limit, room > 0 ? room : 0);
     err = m;
     return false;
   }
@@ -945,7 +949,8 @@ extern "C" int qh_build_write_shard(qh_build* h, const char* path, int argc, con
   qh_header_fill_standard(fh, argc, argv);
   std::string hdr;
   qh_header_serialize(fh, hdr);
-  int fd = open(path, write_header ? (O_WRONLY | O_CREAT | O_TRUNC) : O_WRONLY, 0644);
+  // read-write: the boundary words of the values image are completed by read-OR-write (see below)
+  int fd = open(path, write_header ? (O_RDWR | O_CREAT | O_TRUNC) : O_RDWR, 0644);
   if (fd < 0) return qh_fail(QH_EIO, "Failed to open output file '%s'.", path);  // create_database.cc:113-115
   bool ok = true;
   if (write_header) {
@@ -1009,9 +1014,13 @@ extern "C" int qh_build_write_shard(qh_build* h, const char* path, int argc, con
       // boundary words are shared with the neighbouring shards: OR into what is there
       uint64_t edge;
       if (pread(fd, &edge, 8, voff) == 8) vimg.front() |= edge;
-      if (vimg.size() > 1 && pread(fd, &edge, 8, voff + (off_t)(vimg.size() - 1) * 8) == 8) vimg.back() |= edge;
+      else ok = false;
+      if (vimg.size() > 1) {
+        if (pread(fd, &edge, 8, voff + (off_t)(vimg.size() - 1) * 8) == 8) vimg.back() |= edge;
+        else ok = false;
+      }
     }
-    ok = write_all(fd, vimg.data(), vimg.size() * 8, voff) == 0;
+    if (ok) ok = write_all(fd, vimg.data(), vimg.size() * 8, voff) == 0;
   }
   if (close(fd) != 0) ok = false;
   if (!ok) return qh_fail(QH_EIO, "Failed to write output file '%s': %s", path, strerror(errno));

@@ -1239,6 +1239,19 @@ static int enqueue_correct(qh_corrector* c, const uint8_t* dev_buf, size_t len, 
   return QH_OK;
 }
 
+// An error-log entry keeps the position of a substitution or truncation in 24 bits (EC_POS): a read of 2^24 bases or
+// more would corrupt its log. Such a read rejects the chunk (QH_EFORMAT) before anything is corrected.
+#define EC_MAX_READ_LEN (1u << 24)
+__global__ __launch_bounds__(256) void k_ec_check_lengths(const uint4* __restrict__ recs, qh_meta* __restrict__ meta) {
+  if (meta->format_err) return;
+  const uint32_t nrec = meta->nrec;
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nrec; r += gridDim.x * blockDim.x)
+    if (recs[r].y >= EC_MAX_READ_LEN) {
+      atomicOr(&meta->format_err, QH_FMT_LINE_TOO_LONG);
+      atomicMin(&meta->first_bad, r);
+    }
+}
+
 static int correct_device_on(qh_corrector* c, const void* dev_buf, size_t len) {
   if (len == 0) return qh_fail(QH_EBADARG, "empty chunk");
   if (!dev_buf || ((uintptr_t)dev_buf & 15)) return qh_fail(QH_EBADARG, "device chunk must be non-null and 16-byte aligned");
@@ -1254,6 +1267,7 @@ static int correct_device_on(qh_corrector* c, const void* dev_buf, size_t len) {
   QH_HIP(hipMemsetAsync(c->d_meta, 0, sizeof(qh_meta), c->stream));
   qh_launch_index_fastq((const uint8_t*)dev_buf, len, c->d_tiles, c->d_nlplane, c->d_recs, (uint32_t)rec_cap, c->d_meta,
                         nullptr, 0, c->stream);
+  hipLaunchKernelGGL(k_ec_check_lengths, dim3(256), dim3(256), 0, c->stream, c->d_recs, c->d_meta);
   // log words: seq_off + 4 r + len + 4 <= len_chunk + 4 nrec + 8, nrec <= len / 6 for non-empty 4-line records
   return enqueue_correct(c, (const uint8_t*)dev_buf, len, (uint32_t)rec_cap, nullptr, len + 4 * (len / 6 + 2) + 64);
 }
@@ -1278,6 +1292,7 @@ static const char* format_error_text(uint32_t err) {
   if (err & QH_FMT_NO_PLUS) return "Invalid fastq file: '+' line missing (multi-line record?)";
   if (err & QH_FMT_LEN_MISMATCH) return "Invalid fastq file: wrong number of quals";
   if (err & QH_FMT_EMPTY_TAIL) return "empty read";
+  if (err & QH_FMT_LINE_TOO_LONG) return "a read of 2^24 bases or more (the error log keeps positions in 24 bits)";
   return "too many records";
 }
 
@@ -1376,6 +1391,9 @@ extern "C" int qh_corrector_correct_fastq(qh_corrector* c, const char* buf, size
   for (size_t i = 0; i < recs.size(); ++i) {
     if (recs[i].reserved & 1u) recs[i].seq_off += (uint32_t)eo;
     if (recs[i].reserved & 2u) recs[i].qual_off += (uint32_t)eo;
+    if (recs[i].len >= EC_MAX_READ_LEN)
+      return qh_fail(QH_EFORMAT, "read %zu of the chunk has %u bases: the corrector takes reads shorter than 2^24 bases "
+                                 "(its error log keeps positions in 24 bits)", i, recs[i].len);
     if (log_words + recs[i].len + 4 > 0xFFFFFFF0ull) return qh_fail(QH_EBADARG, "chunk too large for the error logs");
     recs[i].reserved = (uint32_t)log_words;  // becomes .w of the device record: the read's log offset
     log_words += (size_t)recs[i].len + 4;

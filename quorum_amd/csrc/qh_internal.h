@@ -1,6 +1,7 @@
 // qh_internal.h -- handle definitions shared by qh_build.hip and qh_query.hip.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -55,12 +56,25 @@ struct qh_query {
   hipStream_t stream = nullptr;
   qh_meta* d_meta = nullptr;
   qh_meta* h_meta = nullptr;
-  // staging for the host-pointer entry points
-  void* d_in = nullptr;  size_t in_cap = 0;
-  void* d_in2 = nullptr; size_t in2_cap = 0;
+  // staging for the host-pointer entry points of the table reductions (stats, histogram, dump): one caller at a time
   void* d_out = nullptr; size_t out_cap = 0;
   std::mutex mu;
+  // The batched lookups (operator[], get_val, get_best_alternatives, is_contaminant) are const and called concurrently by
+  // the corrector's threads upstream (src/mer_database.hpp:284, src/error_correct_reads.cc:114,173-175): every call takes
+  // a LANE of its own -- a stream and staging buffers -- so that concurrent callers overlap on the GPU instead of
+  // queueing on one mutex. Lanes are created on demand, QH_QUERY_MAX_LANES at most; further callers wait for a free one.
+  struct lane {
+    hipStream_t stream = nullptr;
+    void* d_in = nullptr;  size_t in_cap = 0;
+    void* d_in2 = nullptr; size_t in2_cap = 0;
+    void* d_out = nullptr; size_t out_cap = 0;
+    bool busy = false;
+  };
+  std::vector<lane*> lanes;
+  std::mutex lane_mu;
+  std::condition_variable lane_cv;
 };
+#define QH_QUERY_MAX_LANES 16
 
 int qh_query_from_table(int device, uint64_t* table, const qh_geom& g, qh_query** out);
 int qh_table_dump(int device, hipStream_t stream, const uint64_t* table, const qh_geom& g, qh_meta* d_meta,

@@ -105,12 +105,34 @@ extern "C" int qh_db_header_info(const char* path, qh_db_info* info) {
   return QH_OK;
 }
 
+extern "C" int qh_db_header_parse(const void* data, size_t len, qh_db_info* info) {
+  if (!data || !info) return qh_fail(QH_EBADARG, "null argument");
+  qh_file_header fh;
+  std::string err;
+  if (!qh_header_parse(static_cast<const char*>(data), len, fh, err)) return qh_fail(QH_EFORMAT, "Can't parse header: %s", err.c_str());
+  memset(info, 0, sizeof *info);
+  info->size = fh.size; info->key_len = fh.key_len; info->val_len = fh.val_len;
+  info->max_reprobe = fh.max_reprobe; info->bits = fh.bits;
+  info->key_bytes = fh.key_bytes; info->value_bytes = fh.value_bytes; info->offset = fh.offset;
+  info->shard_bits = fh.shard_bits; info->window_bits = fh.window_bits;
+  snprintf(info->format, sizeof info->format, "%s", fh.format.c_str());
+  if (fh.format != "binary/quorum_db") return qh_fail(QH_EFORMAT, "Wrong type '%s'", fh.format.c_str());
+  return QH_OK;
+}
+
 extern "C" void qh_query_close(qh_query* q) {
   if (!q) return;
   hipError_t e = hipSetDevice(q->device); (void)e;
   if (q->stream) { e = hipStreamSynchronize(q->stream); (void)e; }
-  void* ptrs[] = {q->owns_table ? (void*)q->table : nullptr, q->d_meta, q->d_in, q->d_in2, q->d_out};
+  void* ptrs[] = {q->owns_table ? (void*)q->table : nullptr, q->d_meta, q->d_out};
   for (void* p : ptrs) if (p) { e = hipFree(p); (void)e; }
+  for (qh_query::lane* l : q->lanes) {
+    if (l->stream) { e = hipStreamSynchronize(l->stream); (void)e; }
+    void* lp[] = {l->d_in, l->d_in2, l->d_out};
+    for (void* p : lp) if (p) { e = hipFree(p); (void)e; }
+    if (l->stream) { e = hipStreamDestroy(l->stream); (void)e; }
+    delete l;
+  }
   if (q->h_meta) { e = hipHostFree(q->h_meta); (void)e; }
   if (q->stream) { e = hipStreamDestroy(q->stream); (void)e; }
   delete q;
@@ -134,20 +156,58 @@ extern "C" int qh_query_batch_device(qh_query* q, const uint64_t* dev_mers, size
   return QH_OK;
 }
 
+// a lane of the handle for the duration of one call (qh_internal.h)
+namespace {
+class lane_guard {
+  qh_query* q_;
+  qh_query::lane* l_ = nullptr;
+public:
+  explicit lane_guard(qh_query* q) : q_(q) {
+    std::unique_lock<std::mutex> lk(q->lane_mu);
+    for (;;) {
+      for (qh_query::lane* l : q->lanes) if (!l->busy) { l_ = l; break; }
+      if (l_) break;
+      if (q->lanes.size() < QH_QUERY_MAX_LANES) {
+        qh_query::lane* l = new qh_query::lane();
+        if (hipSetDevice(q->device) != hipSuccess || hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess) {
+          (void)hipGetLastError();
+          delete l;
+          if (q->lanes.empty()) return;  // no lane at all: the caller reports the failure
+        } else {
+          q->lanes.push_back(l);
+          l_ = l;
+          break;
+        }
+      }
+      q->lane_cv.wait(lk);
+    }
+    l_->busy = true;
+  }
+  ~lane_guard() {
+    if (!l_) return;
+    { std::lock_guard<std::mutex> lk(q_->lane_mu); l_->busy = false; }
+    q_->lane_cv.notify_one();
+  }
+  qh_query::lane* get() const { return l_; }
+};
+}  // namespace
+
 static int lookup_host(qh_query* q, const uint64_t* mers, size_t n, uint64_t* out, int get_val) {
   if (!q) return qh_fail(QH_EBADARG, "null handle");
   if (n == 0) return QH_OK;
   if (!mers || !out) return qh_fail(QH_EBADARG, "null buffer");
-  std::lock_guard<std::mutex> lock(q->mu);
+  lane_guard lg(q);
+  qh_query::lane* l = lg.get();
+  if (!l) return qh_fail(QH_EHIP, "cannot create a stream for the lookup");
   QH_HIP(hipSetDevice(q->device));
   int rc;
-  if ((rc = qh_ensure_device(&q->d_in, &q->in_cap, n * 8, "query keys"))) return rc;
-  if ((rc = qh_ensure_device(&q->d_out, &q->out_cap, n * 8, "query results"))) return rc;
-  QH_HIP(hipMemcpyAsync(q->d_in, mers, n * 8, hipMemcpyHostToDevice, q->stream));
-  qh_launch_lookup(q->table, q->g, (const uint64_t*)q->d_in, n, (uint64_t*)q->d_out, get_val, q->stream);
+  if ((rc = qh_ensure_device(&l->d_in, &l->in_cap, n * 8, "query keys"))) return rc;
+  if ((rc = qh_ensure_device(&l->d_out, &l->out_cap, n * 8, "query results"))) return rc;
+  QH_HIP(hipMemcpyAsync(l->d_in, mers, n * 8, hipMemcpyHostToDevice, l->stream));
+  qh_launch_lookup(q->table, q->g, (const uint64_t*)l->d_in, n, (uint64_t*)l->d_out, get_val, l->stream);
   QH_HIP(hipGetLastError());
-  QH_HIP(hipMemcpyAsync(out, q->d_out, n * 8, hipMemcpyDeviceToHost, q->stream));
-  QH_HIP(hipStreamSynchronize(q->stream));
+  QH_HIP(hipMemcpyAsync(out, l->d_out, n * 8, hipMemcpyDeviceToHost, l->stream));
+  QH_HIP(hipStreamSynchronize(l->stream));
   return QH_OK;
 }
 
@@ -164,27 +224,29 @@ extern "C" int qh_query_best_alternatives_batch(qh_query* q, const uint64_t* fme
   if (!q) return qh_fail(QH_EBADARG, "null handle");
   if (n == 0) return QH_OK;
   if (!fmers || !backward || !counts || !ucode || !level || !nkept) return qh_fail(QH_EBADARG, "null buffer");
-  std::lock_guard<std::mutex> lock(q->mu);
+  lane_guard lg(q);
+  qh_query::lane* l = lg.get();
+  if (!l) return qh_fail(QH_EHIP, "cannot create a stream for the lookup");
   QH_HIP(hipSetDevice(q->device));
   int rc;
   // d_in: fmers; d_in2: backward flags; d_out: counts[n][4] then ucode, level, nkept
-  if ((rc = qh_ensure_device(&q->d_in, &q->in_cap, n * 8, "query keys"))) return rc;
-  if ((rc = qh_ensure_device(&q->d_in2, &q->in2_cap, n, "direction flags"))) return rc;
-  if ((rc = qh_ensure_device(&q->d_out, &q->out_cap, n * (32 + 12), "query results"))) return rc;
-  uint64_t* d_counts = (uint64_t*)q->d_out;
+  if ((rc = qh_ensure_device(&l->d_in, &l->in_cap, n * 8, "query keys"))) return rc;
+  if ((rc = qh_ensure_device(&l->d_in2, &l->in2_cap, n, "direction flags"))) return rc;
+  if ((rc = qh_ensure_device(&l->d_out, &l->out_cap, n * (32 + 12), "query results"))) return rc;
+  uint64_t* d_counts = (uint64_t*)l->d_out;
   int32_t* d_ucode = (int32_t*)(d_counts + n * 4);
   int32_t* d_level = d_ucode + n;
   int32_t* d_nkept = d_level + n;
-  QH_HIP(hipMemcpyAsync(q->d_in, fmers, n * 8, hipMemcpyHostToDevice, q->stream));
-  QH_HIP(hipMemcpyAsync(q->d_in2, backward, n, hipMemcpyHostToDevice, q->stream));
-  qh_launch_best_alternatives(q->table, q->g, (const uint64_t*)q->d_in, (const uint8_t*)q->d_in2, n, d_counts, d_ucode,
-                              d_level, d_nkept, q->stream);
+  QH_HIP(hipMemcpyAsync(l->d_in, fmers, n * 8, hipMemcpyHostToDevice, l->stream));
+  QH_HIP(hipMemcpyAsync(l->d_in2, backward, n, hipMemcpyHostToDevice, l->stream));
+  qh_launch_best_alternatives(q->table, q->g, (const uint64_t*)l->d_in, (const uint8_t*)l->d_in2, n, d_counts, d_ucode,
+                              d_level, d_nkept, l->stream);
   QH_HIP(hipGetLastError());
-  QH_HIP(hipMemcpyAsync(counts, d_counts, n * 32, hipMemcpyDeviceToHost, q->stream));
-  QH_HIP(hipMemcpyAsync(ucode, d_ucode, n * 4, hipMemcpyDeviceToHost, q->stream));
-  QH_HIP(hipMemcpyAsync(level, d_level, n * 4, hipMemcpyDeviceToHost, q->stream));
-  QH_HIP(hipMemcpyAsync(nkept, d_nkept, n * 4, hipMemcpyDeviceToHost, q->stream));
-  QH_HIP(hipStreamSynchronize(q->stream));
+  QH_HIP(hipMemcpyAsync(counts, d_counts, n * 32, hipMemcpyDeviceToHost, l->stream));
+  QH_HIP(hipMemcpyAsync(ucode, d_ucode, n * 4, hipMemcpyDeviceToHost, l->stream));
+  QH_HIP(hipMemcpyAsync(level, d_level, n * 4, hipMemcpyDeviceToHost, l->stream));
+  QH_HIP(hipMemcpyAsync(nkept, d_nkept, n * 4, hipMemcpyDeviceToHost, l->stream));
+  QH_HIP(hipStreamSynchronize(l->stream));
   return QH_OK;
 }
 
@@ -245,19 +307,21 @@ extern "C" int qh_query_batch_contaminant(qh_query* q, qh_query* contaminant, co
   if (!q || !contaminant) return qh_fail(QH_EBADARG, "null handle");
   if (n == 0) return QH_OK;
   if (!mers || !flags) return qh_fail(QH_EBADARG, "null buffer");
-  std::lock_guard<std::mutex> lock(q->mu);
+  lane_guard lg(q);
+  qh_query::lane* l = lg.get();
+  if (!l) return qh_fail(QH_EHIP, "cannot create a stream for the lookup");
   QH_HIP(hipSetDevice(q->device));
   int rc;
-  if ((rc = qh_ensure_device(&q->d_in, &q->in_cap, n * 8, "query keys"))) return rc;
-  if ((rc = qh_ensure_device(&q->d_in2, &q->in2_cap, n, "contaminant flags"))) return rc;
-  if ((rc = qh_ensure_device(&q->d_out, &q->out_cap, n * 8, "query results"))) return rc;
-  QH_HIP(hipMemcpyAsync(q->d_in, mers, n * 8, hipMemcpyHostToDevice, q->stream));
-  if ((rc = qh_query_batch_contaminant_device(q, contaminant, (const uint64_t*)q->d_in, n, out ? (uint64_t*)q->d_out : nullptr,
-                                              (uint8_t*)q->d_in2, q->stream)))
+  if ((rc = qh_ensure_device(&l->d_in, &l->in_cap, n * 8, "query keys"))) return rc;
+  if ((rc = qh_ensure_device(&l->d_in2, &l->in2_cap, n, "contaminant flags"))) return rc;
+  if ((rc = qh_ensure_device(&l->d_out, &l->out_cap, n * 8, "query results"))) return rc;
+  QH_HIP(hipMemcpyAsync(l->d_in, mers, n * 8, hipMemcpyHostToDevice, l->stream));
+  if ((rc = qh_query_batch_contaminant_device(q, contaminant, (const uint64_t*)l->d_in, n, out ? (uint64_t*)l->d_out : nullptr,
+                                              (uint8_t*)l->d_in2, l->stream)))
     return rc;
-  if (out) QH_HIP(hipMemcpyAsync(out, q->d_out, n * 8, hipMemcpyDeviceToHost, q->stream));
-  QH_HIP(hipMemcpyAsync(flags, q->d_in2, n, hipMemcpyDeviceToHost, q->stream));
-  QH_HIP(hipStreamSynchronize(q->stream));
+  if (out) QH_HIP(hipMemcpyAsync(out, l->d_out, n * 8, hipMemcpyDeviceToHost, l->stream));
+  QH_HIP(hipMemcpyAsync(flags, l->d_in2, n, hipMemcpyDeviceToHost, l->stream));
+  QH_HIP(hipStreamSynchronize(l->stream));
   return QH_OK;
 }
 

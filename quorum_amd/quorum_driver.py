@@ -57,8 +57,9 @@ FLAGS = ["trim-contaminant", "no-discard"]                                      
 def detect_min_q_char(path):
     lib = ctypes.CDLL(os.path.join(HERE, "csrc", "libquorum_hip.so"))
     lib.qh_last_error.restype = ctypes.c_char_p
+    import itertools
     with open(path, "rb") as f:
-        head = f.read(4 << 20)  # far more than 4000 lines of a read file
+        head = b"".join(itertools.islice(f, 4000))  # header lines 1..4000 = the first 1000 records (quorum.in:133-144)
     c = ctypes.c_int()
     if lib.qh_detect_min_qual_char(head, ctypes.c_size_t(len(head)), ctypes.byref(c)) != 0:
         sys.stderr.write(lib.qh_last_error().decode() + "\n")

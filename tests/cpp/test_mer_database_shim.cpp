@@ -7,6 +7,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <sys/stat.h>
+#include <atomic>
+#include <fstream>
 #include <map>
 #include <string>
 #include <thread>
@@ -107,11 +109,27 @@ int main(int argc, char* argv[]) {
       th_hq2_1.join(); th_hq2_2.join(); th_hq1_1.join(); th_lqhq_0.join(); th_lqhq_1.join();
       th_lqhq_2.join(); th_lqhq_3.join(); th_lq1_1.join(); th_lq2_1.join(); th_lq2_2.join();
     }
-    database.write(path);
+    // the stream form, as unit_tests/test_mer_database.cc:97-101: write(os, &header) fills the caller's header
+    std::ofstream file(path);
+    database_header wheader;
+    database.write(file, &wheader);
+    file.close();
+    EXPECT(file.good());
+    EXPECT(wheader.bits() == bits);
+    EXPECT(wheader.offset() % sizeof(uint64_t) == 0);
   }
   database_header header;
   EXPECT(header.read(path));
   EXPECT(header.offset() % sizeof(uint64_t) == 0);                                             // :102
+  {
+    // database_header::read(std::istream&), as database_query::parse_header does (src/mer_database.hpp:257-267)
+    std::ifstream in(path);
+    database_header sheader;
+    EXPECT(sheader.read(in));
+    EXPECT(sheader.check_format());
+    EXPECT(sheader.offset() == header.offset() && sheader.key_bytes() == header.key_bytes() && sheader.bits() == header.bits());
+    EXPECT((size_t)in.tellg() == header.offset());   // the stream stands where the keys image starts
+  }
   struct stat st;
   EXPECT(stat(path, &st) == 0);
   EXPECT((size_t)st.st_size == header.offset() + header.key_bytes() + header.value_bytes());   // :103-106
@@ -126,6 +144,27 @@ int main(int argc, char* argv[]) {
   test_sequence(database, hqlq, 1, 1, "hqlq", mer_map);
   test_sequence(database, lq1, 1, 0, "lq1", mer_map);
   test_sequence(database, lq2, 2, 0, "lq2", mer_map);
+  {
+    // the const lookups are called concurrently by the corrector's threads upstream (error_correct_reads.cc:114,173-175)
+    std::atomic<int> wrong(0);
+    auto hammer = [&](const std::string* seq, uint64_t count, int quality, unsigned seed) {
+      mer_dna m;
+      for (int i = 0; i < 300; ++i) {
+        seed = seed * 1664525u + 1013904223u;
+        m = seq->substr(seed % (seq->size() - mer_dna::k()), mer_dna::k());
+        const std::pair<uint64_t, int> res = database[m];
+        if (res.first != count || res.second != quality) ++wrong;
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < 12; ++t) {
+      if (t % 3 == 0) th.emplace_back(hammer, &hq2, 2, 1, t);
+      else if (t % 3 == 1) th.emplace_back(hammer, &lq1, 1, 0, t);
+      else th.emplace_back(hammer, &hqlq, 1, 1, t);
+    }
+    for (auto& t : th) t.join();
+    EXPECT(wrong.load() == 0);
+  }
   size_t n = 0;
   for (database_query::const_iterator it = database.begin(); it != database.end(); ++it, ++n) {  // :123-134
     mer_map_t::const_iterator counts = mer_map.find(it->first.word());

@@ -273,3 +273,31 @@ def test_corrected_reads_come_from_the_genome(bacterial):
     raw_ok = sum(1 for s in raw if s in gs or s in grc)
     assert ok > 0.97 * st["corrected"] and raw_ok < 0.5 * len(raw)
     ec.close()
+
+
+def test_read_of_2pow24_bases_is_rejected():
+    """the error log keeps positions in 24 bits: a read of 2^24 bases or more must reject the chunk (QH_EFORMAT) on the
+    device-indexed path and on the host-parsed path instead of corrupting its log"""
+    import torch
+    from quorum_amd import _lib
+    rng = np.random.default_rng(3)
+    small = random_fastq(rng, 200, k=24)
+    odb, h, q = build_pair(small, 24)
+    n = (1 << 24) + 5
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].tobytes()
+    big = b"@long\n" + seq + b"\n+\n" + b"I" * n + b"\n"
+    ec = qa.ErrorCorrector(q, cutoff=4)
+    with pytest.raises(_lib.QhError) as e:      # fast path rejects on the GPU, the host parser then names the read
+        ec.correct_fastq(small + big)
+    assert e.value.status == _lib.QH_EFORMAT and "2^24" in str(e.value)
+    t = torch.frombuffer(bytearray(small + big), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    ec.correct_device(t.data_ptr(), t.numel())
+    with pytest.raises(_lib.QhError) as e:
+        ec.fetch()
+    assert e.value.status == _lib.QH_EFORMAT and "2^24" in str(e.value)
+    # one base fewer is fine
+    ok = b"@long\n" + seq[:(1 << 24) - 1] + b"\n+\n" + b"I" * ((1 << 24) - 1) + b"\n"
+    fa, lg, st, used = ec.correct_fastq(small + ok)
+    assert used == len(small + ok) and st["reads"] == 201
+    ec.close()

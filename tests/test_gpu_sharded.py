@@ -17,9 +17,11 @@ from helpers import sorted_pairs
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("shard_bits", [1, 2, 3])
-def test_sharded_build_single_process(shard_bits, tmp_path):
-    k, bits, thresh = 24, 7, 38
+@pytest.mark.parametrize("shard_bits,bits", [(1, 7), (2, 6), (3, 7), (3, 2)])
+def test_sharded_build_single_process(shard_bits, bits, tmp_path):
+    # bits 6 and 2: value fields of 7 and 3 bits do not pack evenly into 64-bit words, so neighbouring shards share
+    # boundary words of the values image (completed by read-OR-write, one writer at a time)
+    k, thresh = 24, 38
     n = 1 << shard_bits
     g = synth.make_genome(200_000)
     fq = synth.make_fastq(g, 40_000, 100, tails=True)
@@ -74,6 +76,14 @@ def test_sharded_build_single_process(shard_bits, tmp_path):
     assert (q.lookup(om[::7]) == ov[::7]).all()
     assert q.stats() == db.stats()
     q.close()
+    # the values image as compute_poisson_cutoff__ scans it (atomic_bits_array layout over ALL slots of the file)
+    info = _lib.QhDbInfo()
+    _lib.check(_lib.lib.qh_db_header_info(path.encode(), C.byref(info)))
+    raw = np.fromfile(path, dtype=np.uint64, offset=info.offset + info.key_bytes)
+    vpw, vb = 64 // (bits + 1), bits + 1
+    fields = (raw[:, None] >> (np.arange(vpw, dtype=np.uint64) * np.uint64(vb))[None, :]) & np.uint64((1 << vb) - 1)
+    fields = fields.reshape(-1)[:info.size]
+    assert int((fields != 0).sum()) == om.size and np.array_equal(np.sort(fields[fields != 0]), np.sort(ov))
     for h in hs:
         h.close()
 
