@@ -201,8 +201,11 @@ __device__ __forceinline__ void qp_spill(const qp_params& p, uint64_t item) {
 // OWNER: items are checked against the shard that owns them (p.check_owner); KCLASS: 2 is k < 4 (no core in the
 // hash; 0 and 1 are compiled alike). Both are the same for
 // every item of a launch, and the extraction loop is bound by the instructions it issues per k-mer.
-template <int SRC, bool OWNER, int KCLASS>
+// KFIX: the mer length when it is known at compile time (24 = the quorum driver's default, 31), else 0: shift counts
+// and masks of the extraction loop fold into the instructions.
+template <int SRC, bool OWNER, int KCLASS, int KFIX = 0>
 __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, const qh_geom g) {
+  const int K = KFIX ? KFIX : g.k;
   __shared__ uint64_t sorted[QP_TILE_ITEMS];
   __shared__ uint32_t cursor[QP_MAX_BINS];  // histogram, then running placement cursor
   __shared__ uint32_t offs[QP_MAX_BINS];    // exclusive prefix of the histogram
@@ -285,16 +288,16 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
       // from the sequence bytes, h from the quality bytes.
       const uint32_t o = sd_cur.x & 63u, oq = (sd_cur.x + (sd_cur.y >> 4)) & 63u, cnt = sd_cur.y & 15u;
       if (cnt) {
-        const uint32_t kones = (uint32_t)((1ull << g.k) - 1);
+        const uint32_t kones = (uint32_t)((1ull << K) - 1);
         auto fun = [&](const uint4& w2, uint32_t sh) -> uint64_t {
           const uint64_t lo = ((uint64_t)w2.y << 32) | w2.x, hi = ((uint64_t)w2.w << 32) | w2.z;
           return (lo >> sh) | ((hi << 1) << (63 - sh));
         };
         // bases past the segment's last k-mer count as no bases: the windows past its count are then invalid
-        const uint64_t wv = fun(pl[0], o) & ((1ull << (cnt + g.k - 1)) - 1), w0 = fun(pl[1], o), w1 = fun(pl[2], o), wh = fun(pl[3], oq);
+        const uint64_t wv = fun(pl[0], o) & ((1ull << (cnt + K - 1)) - 1), w0 = fun(pl[1], o), w1 = fun(pl[2], o), wh = fun(pl[3], oq);
         // forward orientation: bit-reversed planes, aligned so that the newest base of k-mer j sits
         // at bit QP_SEG-1-j
-        const int sh0 = 64 - g.k - (QP_SEG - 1);
+        const int sh0 = 64 - K - (QP_SEG - 1);
         const uint64_t f0 = __builtin_bitreverse64(w0) >> sh0, f1 = __builtin_bitreverse64(w1) >> sh0;
 #pragma unroll
         for (int j = 0; j < QP_SEG; ++j) {
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
             const uint32_t q = ((uint32_t)(wh >> j) & kones) == kones;         // high_len >= k (:86)
             const uint32_t r0 = ~(uint32_t)(w0 >> j) & kones, r1 = ~(uint32_t)(w1 >> j) & kones;
             const uint32_t m0 = (uint32_t)(f0 >> (QP_SEG - 1 - j)) & kones, m1 = (uint32_t)(f1 >> (QP_SEG - 1 - j)) & kones;
-            const uint64_t h = qh_hash_strands_form<KCLASS == 2>(m0, m1, r0, r1, g.k);  // min(m, rm) of create_database.cc:86, hashed
+            const uint64_t h = qh_hash_strands_form<KCLASS == 2>(m0, m1, r0, r1, K);  // min(m, rm) of create_database.cc:86, hashed
             if (OWNER && ((uint32_t)h & smask) != (uint32_t)g.shard_id) {
               ++n_foreign;
             } else {
@@ -436,15 +439,19 @@ void qh_launch_partition_fastq(const qh_fastq_aux& a, uint32_t rec_cap, qh_meta*
   p.seg_total = a.tile_sums + (rec_cap + RB_TILE - 1) / RB_TILE;
   const dim3 grid(256), block(QP_THREADS);
   const int kclass = g.k < 4 ? 2 : g.k < QP_SEG ? 1 : 0;
-#define QP_LAUNCH_FASTQ(OWNER, KC) hipLaunchKernelGGL((k_partition<QP_SRC_FASTQ, OWNER, KC>), grid, block, 0, s, p, g)
+#define QP_LAUNCH_FASTQ(OWNER, KC, KF) hipLaunchKernelGGL((k_partition<QP_SRC_FASTQ, OWNER, KC, KF>), grid, block, 0, s, p, g)
+  static const char* nofix = getenv("QH_NO_KFIX");  // A/B tests
+  const int kfix = nofix ? 0 : g.k;
   if (check_owner) {
-    if (kclass == 2) QP_LAUNCH_FASTQ(true, 2);
-    else if (kclass == 1) QP_LAUNCH_FASTQ(true, 1);
-    else QP_LAUNCH_FASTQ(true, 0);
+    if (kclass == 2) QP_LAUNCH_FASTQ(true, 2, 0);
+    else if (kclass == 1) QP_LAUNCH_FASTQ(true, 1, 0);
+    else if (kfix == 24) QP_LAUNCH_FASTQ(true, 0, 24);
+    else QP_LAUNCH_FASTQ(true, 0, 0);
   } else {
-    if (kclass == 2) QP_LAUNCH_FASTQ(false, 2);
-    else if (kclass == 1) QP_LAUNCH_FASTQ(false, 1);
-    else QP_LAUNCH_FASTQ(false, 0);
+    if (kclass == 2) QP_LAUNCH_FASTQ(false, 2, 0);
+    else if (kclass == 1) QP_LAUNCH_FASTQ(false, 1, 0);
+    else if (kfix == 24) QP_LAUNCH_FASTQ(false, 0, 24);
+    else QP_LAUNCH_FASTQ(false, 0, 0);
   }
 #undef QP_LAUNCH_FASTQ
 }
