@@ -161,6 +161,22 @@ int qh_build_write(qh_build* h, const char* path, int argc, const char* const* a
 int qh_build_write_shard(qh_build* h, const char* path, int argc, const char* const* argv,
                          int write_header);
 
+/* The same database with the keys image in the layout of jellyfish::large_hash::array as far as it could be
+ * restated without the library (what hash_with_quality::write dumps upstream, src/mer_database.hpp:115-126, and
+ * database_query wraps, :273-277): GF(2) matrix position, quadratic reprobes, bit-packed (high key bits, reprobe)
+ * entries; header with "matrix1" and "reprobes" and no "qhip" object. PARITY UNPINNED and a known deviation (no
+ * "set" bits in straddling words; quorum_amd/csrc/qh_jflayout.h): an upstream reader is NOT expected to decode
+ * it. A serialisation switch for the day it can be checked against Jellyfish, self round-trip tested:
+ * qh_query_open reads such a file (entries decoded on the host, re-inserted into a native table in HBM).
+ * Unsharded handles only; the image is built on the host from the table's content. */
+int qh_build_write_jf(qh_build* h, const char* path, int argc, const char* const* argv);
+/* Host-only halves of the above (no GPU call): n distinct (mer, count<<1|hq) pairs -> file, and back (entry
+ * order; call with cap = 0 and null buffers to size). */
+int qh_jf_write_file(const char* path, int k, int bits, uint64_t size, int reprobe_limit, const uint64_t* mers,
+                     const uint64_t* vals, uint64_t n, int argc, const char* const* argv);
+int qh_jf_read_file(const char* path, int* k, int* bits, uint64_t* size, uint64_t* mers, uint64_t* vals,
+                    uint64_t cap, uint64_t* n);
+
 /* Doubles this shard's table until it has at least 2^lsize slots (used to
  * equalise shard sizes before qh_build_write_shard). */
 int qh_build_grow_to(qh_build* h, int lsize);

@@ -79,6 +79,10 @@ SIGNATURES = [
     ("qh_build_write", C.c_int, [_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p)]),
     ("qh_build_write_shard", C.c_int, [_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_int]),
     ("qh_build_grow_to", C.c_int, [_p, C.c_int]),
+    ("qh_build_write_jf", C.c_int, [_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p)]),
+    ("qh_jf_write_file", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.c_int, _u64p, _u64p, C.c_uint64, C.c_int,
+                                   C.POINTER(C.c_char_p)]),
+    ("qh_jf_read_file", C.c_int, [C.c_char_p, _i32p, _i32p, _u64p, _u64p, _u64p, C.c_uint64, _u64p]),
     ("qh_fastq_4line_prefix", C.c_size_t, [C.c_char_p, C.c_size_t, C.c_int]),
     ("qh_build_dump", C.c_int, [_p, _u64p, _u64p, C.c_uint64, _u64p]),
     ("qh_build_as_query", C.c_int, [_p, C.POINTER(_p)]),

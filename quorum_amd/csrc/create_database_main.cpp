@@ -44,6 +44,7 @@ static const char* kHelp =
     "     --gpu=int                            HIP device to build on (0)\n"
     "     --gpus=int                           Build hash-sharded over this many GPUs (1)\n"
     "     --devices=list                       The HIP devices of the shards, comma separated\n"
+    "     --jf-layout                          Keys image in the (unverified) Jellyfish layout; 1 GPU\n"
     " -U, --usage                              Usage\n"
     " -h, --help                               This message\n"
     " -V, --version                            Version";
@@ -91,6 +92,7 @@ struct args_t {
   int gpu = 0;
   int gpus = 1;
   std::vector<int> devices;
+  bool jf_layout = false;
   std::vector<const char*> reads;
 };
 
@@ -107,6 +109,7 @@ static void parse(int argc, char** argv, args_t& a) {
     if (!strcmp(s, "-h") || !strcmp(s, "--help")) { printf("%s\n\n%s\n", kUsage, kHelp); exit(0); }
     if (!strcmp(s, "-U") || !strcmp(s, "--usage")) { printf("%s\n", kUsage); exit(0); }
     if (!strcmp(s, "-V") || !strcmp(s, "--version")) { printf("%s\n", qh_version()); exit(0); }
+    if (!strcmp(s, "--jf-layout")) { a.jf_layout = true; continue; }
     char key = 0;
     const char* val = nullptr;
     if (s[1] == '-') {
@@ -158,6 +161,7 @@ static void parse(int argc, char** argv, args_t& a) {
   if (a.reads.empty()) error("Requires at least 1 argument.");
   if (!a.devices.empty()) a.gpus = (int)a.devices.size();
   if (a.gpus < 1 || (a.gpus & (a.gpus - 1))) error("The number of GPUs must be a power of two");
+  if (a.jf_layout && a.gpus > 1) error("Switch [--jf-layout] writes from one GPU: not with --gpus / --devices");
 }
 
 [[noreturn]] static void die(const char* what, int rc) {
@@ -370,7 +374,8 @@ int main(int argc, char* argv[]) {
   qh_build_stats st;
   if ((rc = qh_build_finish(h, &st)) != QH_OK) die("create_database", rc);
   const double t_feed = secs();
-  if ((rc = qh_build_write(h, args.output, argc, argv)) != QH_OK) die("create_database", rc);
+  rc = args.jf_layout ? qh_build_write_jf(h, args.output, argc, argv) : qh_build_write(h, args.output, argc, argv);
+  if (rc != QH_OK) die("create_database", rc);
   if (getenv("QUORUM_HIP_VERBOSE"))
     fprintf(stderr, "seconds: device+table %.3f  read+build %.3f  write %.3f\n", t_init, t_feed - t_init, secs() - t_feed);
   if (getenv("QUORUM_HIP_VERBOSE"))

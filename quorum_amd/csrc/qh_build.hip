@@ -1035,6 +1035,21 @@ extern "C" int qh_build_dump(qh_build* h, uint64_t* mers, uint64_t* vals, uint64
   return qh_table_dump(h->device, h->stream, h->table, h->g, h->d_meta, h->h_meta, mers, vals, cap, n);
 }
 
+// The database in the recalled Jellyfish layout (qh_jflayout.h; parity unpinned): the table's entries are read
+// back and the bit-packed image is built on the host -- a serialisation switch, not a hot path.
+extern "C" int qh_build_write_jf(qh_build* h, const char* path, int argc, const char* const* argv) {
+  if (!h || !path) return qh_fail(QH_EBADARG, "null argument");
+  if (h->g.shard_bits) return qh_fail(QH_EBADARG, "qh_build_write_jf on a sharded handle");
+  qh_build_stats st;
+  int rc = qh_build_finish(h, &st);
+  if (rc) return rc;
+  std::vector<uint64_t> mers(st.distinct ? st.distinct : 1), vals(st.distinct ? st.distinct : 1);
+  uint64_t n = 0;
+  if ((rc = qh_build_dump(h, mers.data(), vals.data(), st.distinct, &n))) return rc;
+  if (n != st.distinct) return qh_fail(QH_EHIP, "the table holds %llu entries, %llu were counted", (unsigned long long)n, (unsigned long long)st.distinct);
+  return qh_jf_write_file(path, h->g.k, h->g.bits, 1ull << h->g.lsize, h->reprobe_limit, mers.data(), vals.data(), n, argc, argv);
+}
+
 extern "C" int qh_build_as_query(qh_build* h, qh_query** out) {
   if (h) { int mrc = materialize(h); if (mrc) return mrc; }
   if (!h || !out) return qh_fail(QH_EBADARG, "null argument");

@@ -178,17 +178,33 @@ void qh_header_serialize(qh_file_header& h, std::string& out) {
   jkv(j, "hostname", h.hostname);
   jkv(j, "key_bytes", h.key_bytes);
   jkv(j, "key_len", (uint64_t)h.key_len);
+  const bool jf = h.layout == QH_LAYOUT_JF;
+  if (jf) {  // RectangularBinaryMatrix as the hash's "matrix1" 
+    jescape("matrix1", j); j += ":{";
+    jkv(j, "c", (uint64_t)h.matrix_c);
+    jescape("columns", j); j += ":[";
+    for (size_t i = 0; i < h.matrix_columns.size(); ++i) { if (i) j += ','; j += std::to_string(h.matrix_columns[i]); }
+    j += "],";
+    jkv(j, "r", (uint64_t)h.matrix_r, false);
+    j += "},";
+  }
   jkv(j, "max_reprobe", (uint64_t)h.max_reprobe);
   jkv(j, "pwd", h.pwd);
-  jescape("qhip", j); j += ":{";
-  jkv(j, "hash", h.hash);
-  jkv(j, "layout", h.layout);
-  jkv(j, "probe_bits", (uint64_t)h.probe_bits);
-  jkv(j, "shard_bits", (uint64_t)h.shard_bits);
-  jkv(j, "window_bits", (uint64_t)h.window_bits, false);
-  j += "},";
-  jescape("reprobes", j); j += ":[";  // linear probing inside a window: offsets 0..max_reprobe
-  for (uint32_t i = 0; i <= h.max_reprobe; ++i) { if (i) j += ','; j += std::to_string(i); }
+  if (!jf) {
+    jescape("qhip", j); j += ":{";
+    jkv(j, "hash", h.hash);
+    jkv(j, "layout", h.layout);
+    jkv(j, "probe_bits", (uint64_t)h.probe_bits);
+    jkv(j, "shard_bits", (uint64_t)h.shard_bits);
+    jkv(j, "window_bits", (uint64_t)h.window_bits, false);
+    j += "},";
+  }
+  jescape("reprobes", j); j += ":[";
+  if (jf) {
+    for (size_t i = 0; i < h.reprobes.size(); ++i) { if (i) j += ','; j += std::to_string(h.reprobes[i]); }
+  } else {  // linear probing inside a window: offsets 0..max_reprobe
+    for (uint32_t i = 0; i <= h.max_reprobe; ++i) { if (i) j += ','; j += std::to_string(i); }
+  }
   j += "],";
   jkv(j, "size", h.size);
   jkv(j, "time", h.time);
@@ -234,6 +250,14 @@ bool qh_header_parse(const char* data, size_t len, qh_file_header& h, std::strin
     h.window_bits = (uint32_t)ju(*q, "window_bits");
     h.probe_bits = (uint32_t)ju(*q, "probe_bits");
     h.shard_bits = (uint32_t)ju(*q, "shard_bits");
+  } else if (const jval* m = root.get("matrix1")) {
+    h.layout = QH_LAYOUT_JF;
+    h.matrix_r = (uint32_t)ju(*m, "r");
+    h.matrix_c = (uint32_t)ju(*m, "c");
+    if (const jval* c = m->get("columns"))
+      for (auto& x : c->a) if (x.kind == jval::NUM) h.matrix_columns.push_back(x.u);
+    if (const jval* r = root.get("reprobes"))
+      for (auto& x : r->a) if (x.kind == jval::NUM) h.reprobes.push_back(x.u);
   }
   return true;
 }

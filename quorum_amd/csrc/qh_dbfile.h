@@ -13,7 +13,10 @@
 // keys image : the native table, one little-endian 64-bit slot per entry
 //              (layout in qh_spec.h). It is NOT Jellyfish's bit-packed
 //              large_hash::array image: that layout cannot be verified offline
-//               and the JSON says so in "qhip.layout".
+//               and the JSON says so in "qhip.layout". Behind a switch
+//              (qh_build_write_jf, --jf-layout) the image is written in the recalled
+//              Jellyfish layout instead (qh_jflayout.h, parity unpinned): such a header
+//              has no "qhip" object and carries "matrix1" and the quadratic "reprobes".
 // vals image : jellyfish::atomic_bits_array layout -- (bits+1)-wide fields
 //              "count<<1|hq", floor(64/(bits+1)) per 64-bit word, entry i in word
 //              i / vpw at shift (i % vpw) * (bits+1); what
@@ -23,6 +26,8 @@
 #include <string>
 #include <vector>
 #include "qh_spec.h"
+
+#define QH_LAYOUT_JF "jellyfish/large_hash"   // internal name; never written to a file
 
 struct qh_file_header {
   std::string format;        // "binary/quorum_db"
@@ -37,6 +42,10 @@ struct qh_file_header {
   std::string layout;        // "slot64/1"
   uint32_t window_bits = 0, probe_bits = 0, shard_bits = 0;
   std::string hash;          // "feistel3-core/2"
+  // layout "jellyfish/large_hash" (qh_jflayout.h; no "qhip" object in the JSON): the matrix1 object and reprobes[]
+  uint32_t matrix_r = 0, matrix_c = 0;
+  std::vector<uint64_t> matrix_columns;
+  std::vector<uint64_t> reprobes;
   std::vector<std::string> cmdline;
   std::string hostname, pwd, time, exe_path;
 };

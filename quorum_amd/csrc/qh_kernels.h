@@ -52,6 +52,10 @@ void qh_launch_insert_items(const uint64_t* items, uint64_t n, const unsigned lo
 void qh_launch_rehash(const uint64_t* old_table, const qh_geom& og, uint64_t* new_table,
                       const qh_geom& ng, qh_meta* meta, hipStream_t s);
 
+// n distinct (mer, value) pairs -> table (no shards); meta->rehash_fail when a key found no place
+void qh_launch_insert_valued(const uint64_t* mers, const uint64_t* vals, uint64_t n, uint64_t* table, const qh_geom& g,
+                             qh_meta* meta, hipStream_t s);
+
 // --- radix-partitioned build (qh_partition.hip) -------------------------------------
 // destination of one partition level
 struct qh_part_dst {

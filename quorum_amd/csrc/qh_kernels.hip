@@ -314,6 +314,30 @@ void qh_launch_rehash(const uint64_t* old_table, const qh_geom& og, uint64_t* ne
                      og, new_table, ng, meta);
 }
 
+// distinct (mer, value) pairs -> empty-or-disjoint table (reader of the jellyfish-layout file, qh_query_open)
+__global__ __launch_bounds__(QH_BLOCK) void k_insert_valued(const uint64_t* __restrict__ mers,
+                                                            const uint64_t* __restrict__ vals, uint64_t n,
+                                                            uint64_t* __restrict__ table, const qh_geom g,
+                                                            qh_meta* __restrict__ meta) {
+  const uint64_t wmask = qh_low_mask(g.wbits);
+  for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (uint64_t)gridDim.x * blockDim.x) {
+    const qh_pos p = qh_locate(g, mers[idx] & g.kmask);
+    const uint64_t val = vals[idx] & g.vmask;
+    const uint64_t base = p.home & ~wmask;
+    bool done = false;
+    for (uint32_t i = 0; i <= (uint32_t)g.max_reprobe && !done; ++i) {
+      unsigned long long* slot = reinterpret_cast<unsigned long long*>(table + (base | ((p.home + i) & wmask)));
+      done = atomicCAS(slot, 0ull, (unsigned long long)(((p.tag0 | (i + 1)) << g.vbits) | val)) == 0;
+    }
+    if (!done) meta->rehash_fail = 1;
+  }
+}
+
+void qh_launch_insert_valued(const uint64_t* mers, const uint64_t* vals, uint64_t n, uint64_t* table, const qh_geom& g,
+                             qh_meta* meta, hipStream_t s) {
+  hipLaunchKernelGGL(k_insert_valued, dim3(grid_for(n, QH_BLOCK, 8192)), dim3(QH_BLOCK), 0, s, mers, vals, n, table, g, meta);
+}
+
 // ---------------------------------------------------------------------- read side
 
 // database_query::operator[] (mer_database.hpp:284-293)

@@ -14,6 +14,7 @@
 
 #include "qh_internal.h"
 #include "qh_dbfile.h"
+#include "qh_jflayout.h"
 
 int qh_ensure_device(void** p, size_t* cap, size_t need, const char* what) {
   if (*cap >= need && *p) return QH_OK;
@@ -42,12 +43,56 @@ int qh_query_from_table(int device, uint64_t* table, const qh_geom& g, qh_query*
   return QH_OK;
 }
 
+// A file in the jellyfish layout (qh_jflayout.h, parity unpinned): its entries are decoded on the host and
+// re-inserted, values carried, into a native table of the same size in HBM (doubled while a key finds no place).
+static int open_jf_layout(qh_query** out, const char* path, int device) {
+  std::string err;
+  std::vector<uint64_t> mers, vals;
+  int k = 0, bits = 0;
+  uint64_t size = 0;
+  if (!qh_jf_read_pairs(path, &k, &bits, &size, mers, vals, err)) return qh_fail(QH_EFORMAT, "%s for file '%s'", err.c_str(), path);
+  qh_query* q = new qh_query();
+  q->device = device;
+  int rc = query_init_common(q);
+  if (rc) { qh_query_close(q); return rc; }
+  const uint64_t n = mers.size();
+  uint64_t *d_m = nullptr, *d_v = nullptr;
+  auto cleanup = [&]() { hipError_t x = hipFree(d_m); x = hipFree(d_v); (void)x; };
+  if (n) {
+    hipError_t e = hipMalloc((void**)&d_m, n * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_v, n * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_m, mers.data(), n * 8, hipMemcpyHostToDevice, q->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_v, vals.data(), n * 8, hipMemcpyHostToDevice, q->stream);
+    if (e != hipSuccess) { (void)hipGetLastError(); cleanup(); qh_query_close(q); return qh_fail(QH_ENOMEM, "cannot stage %llu entries on the device: %s", (unsigned long long)n, hipGetErrorString(e)); }
+  }
+  for (uint64_t slots = size;; slots <<= 1) {
+    qh_geom g;
+    if (slots > (1ull << 44) || !qh_make_geom(k, bits, slots, 0, 126, 0, 0, -1, g, err)) { cleanup(); qh_query_close(q); return qh_fail(QH_EFULL, "Hash is full"); }
+    const size_t bytes = (size_t)8 << g.lsize;
+    hipError_t e = hipMalloc((void**)&q->table, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(q->table, 0, bytes, q->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(q->d_meta, 0, sizeof(qh_meta), q->stream);
+    if (e == hipSuccess && n) { qh_launch_insert_valued(d_m, d_v, n, q->table, g, q->d_meta, q->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(q->h_meta, q->d_meta, sizeof(qh_meta), hipMemcpyDeviceToHost, q->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(q->stream);
+    if (e != hipSuccess) { (void)hipGetLastError(); cleanup(); qh_query_close(q); return qh_fail(QH_EHIP, "building the table from '%s' failed: %s", path, hipGetErrorString(e)); }
+    q->g = g;
+    if (!q->h_meta->rehash_fail) break;
+    e = hipFree(q->table); (void)e;
+    q->table = nullptr;
+  }
+  cleanup();
+  *out = q;
+  return QH_OK;
+}
+
 extern "C" int qh_query_open(qh_query** out, const char* path, int device) {
   if (!out || !path) return qh_fail(QH_EBADARG, "null argument");
   *out = nullptr;
   qh_file_header fh;
   std::string err;
   if (!qh_header_read_file(path, fh, err)) return qh_fail(QH_EIO, "%s", err.c_str());
+  if (fh.format == "binary/quorum_db" && fh.layout == QH_LAYOUT_JF) return open_jf_layout(out, path, device);
   qh_geom g;
   if (!qh_geom_from_header(fh, g, err)) return qh_fail(QH_EFORMAT, "%s for file '%s'", err.c_str(), path);
   int fd = open(path, O_RDONLY);

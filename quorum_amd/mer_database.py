@@ -88,6 +88,12 @@ class HashWithQuality:
         arr = (C.c_char_p * max(1, len(argv)))(*[a.encode() for a in argv])
         check(lib.qh_build_write(self._h, str(path).encode(), len(argv), arr))
 
+    def write_jf(self, path, argv=()):
+        """The same database with the keys image in the recalled jellyfish::large_hash::array layout
+        (qh_jflayout.h; PARITY UNPINNED, not checked against any Jellyfish reader or writer)."""
+        arr = (C.c_char_p * max(1, len(argv)))(*[a.encode() for a in argv])
+        check(lib.qh_build_write_jf(self._h, str(path).encode(), len(argv), arr))
+
     # -- chunk entry points (quality_mer_counter::start, create_database.cc:56-95) -----
     def add_fastq(self, data):
         data = bytes(data)
@@ -185,6 +191,28 @@ def detect_min_qual_char(data):
     c = C.c_int()
     check(lib.qh_detect_min_qual_char(data, len(data), C.byref(c)))
     return c.value
+
+
+def jf_write_file(path, k, bits, size, mers, vals, reprobe_limit=126, argv=()):
+    """host-only: n distinct (mer, count<<1|hq) pairs -> a database file whose keys image follows the recalled
+    jellyfish::large_hash::array layout (qh_jflayout.h; PARITY UNPINNED)"""
+    mers, pm = _u64(mers)
+    vals, pv = _u64(vals)
+    arr = (C.c_char_p * max(1, len(argv)))(*[a.encode() for a in argv])
+    check(lib.qh_jf_write_file(str(path).encode(), k, bits, size, reprobe_limit, pm, pv, mers.size, len(argv), arr))
+
+
+def jf_read_file(path):
+    """host-only: (k, bits, size, mers, vals) of a file written by jf_write_file / HashWithQuality.write_jf"""
+    k, bits, size, n = C.c_int32(), C.c_int32(), C.c_uint64(), C.c_uint64()
+    check(lib.qh_jf_read_file(str(path).encode(), C.byref(k), C.byref(bits), C.byref(size), None, None, 0, C.byref(n)))
+    mers = np.empty(n.value, dtype=np.uint64)
+    vals = np.empty(n.value, dtype=np.uint64)
+    if n.value:
+        check(lib.qh_jf_read_file(str(path).encode(), C.byref(k), C.byref(bits), C.byref(size),
+                                  mers.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                  vals.ctypes.data_as(C.POINTER(C.c_uint64)), n.value, C.byref(n)))
+    return k.value, bits.value, size.value, mers, vals
 
 
 def poisson_term(lam, i):
