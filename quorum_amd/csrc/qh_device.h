@@ -240,17 +240,19 @@ __device__ __forceinline__ void qh_canonical_planes(uint32_t m0, uint32_t m1, ui
 // SMALLK: k < 4 (no core: the whole key is hashed); callers in a per-item loop pick the form once
 template <bool SMALLK>
 __device__ __forceinline__ uint64_t qh_hash_strands_form(uint32_t m0, uint32_t m1, uint32_t r0, uint32_t r1, int k) {
-  const uint32_t x0 = m0 ^ r0, x1 = m1 ^ r1, xa = x0 | x1;
-  const int cf = __clz((int)xa) & 31;  // xa == 0 (palindrome): either strand
-  const bool fwd = (int32_t)((((int32_t)(x1 << cf) < 0) ? m1 : m0) << cf) >= 0;
+  // m < r is decided at the most significant base where they differ. lt marks the bases where the forward code is
+  // the smaller one, d the bases that differ at all: lt and d ^ lt are disjoint, so the one that holds the top bit
+  // of d is the larger integer -- no count-leading-zeros, no variable shifts. d == 0 (palindrome): either strand.
+  const uint32_t x1 = m1 ^ r1, d = (m0 ^ r0) | x1;
+  const uint32_t lt = (r1 & ~m1) | (~x1 & r0 & ~m0);
+  const bool fwd = lt > (d ^ lt);
   const uint32_t c0 = fwd ? m0 : r0, c1 = fwd ? m1 : r1;
   if (SMALLK) return qh_feistel3(c0, c1, k);
   const int kc = k - 2;
   const uint32_t cm = (1u << kc) - 1u;
-  const uint32_t xc = xa & (cm << 1), xc1 = x1 & (cm << 1);
-  const int cc = __clz((int)xc) & 31;
+  const uint32_t dc = d & (cm << 1), ltc = lt & (cm << 1);
   // the strand with the smaller core supplies it; equal cores: the key's own strand (no flip)
-  const bool cfwd = xc ? (int32_t)((((int32_t)(xc1 << cc) < 0) ? m1 : m0) << cc) >= 0 : fwd;
+  const bool cfwd = (ltc > (dc ^ ltc)) | ((dc == 0) & fwd);
   const uint32_t cL = ((cfwd ? m0 : r0) >> 1) & cm, cR = ((cfwd ? m1 : r1) >> 1) & cm;
   const uint32_t e = (c0 & 1u) | ((c1 & 1u) << 1) | ((c0 >> (k - 1)) << 2) | ((c1 >> (k - 1)) << 3);
   return (qh_feistel3(cL, cR, kc) ^ QH_MIX_Z) | ((uint64_t)(e | ((uint32_t)(fwd != cfwd) << 4)) << (2 * kc));

@@ -170,6 +170,7 @@ struct qp_params {
   uint32_t out_count_stride;  // counters of consecutive buckets lie this many words apart (contention, see qh_kernels.h)
   int bin_shift;       // bin = (h >> bin_shift) & bin_mask
   uint32_t bin_mask;
+  uint32_t bin_bits;
   int out_bin_shift;   // ob = (input bucket << out_bin_shift) | bin
   uint64_t* spill;     // items that do not fit their bucket (meta->spill_count), inserted directly later
   uint64_t spill_cap;
@@ -203,9 +204,15 @@ __device__ __forceinline__ void qp_spill(const qp_params& p, uint64_t item) {
 // every item of a launch, and the extraction loop is bound by the instructions it issues per k-mer.
 // KFIX: the mer length when it is known at compile time (24 = the quorum driver's default, 31), else 0: shift counts
 // and masks of the extraction loop fold into the instructions.
-template <int SRC, bool OWNER, int KCLASS, int KFIX = 0>
+// BINLO: the bin field of (hash << 1 | q) lies in the low 32 bits (bin_shift + bin_bits <= 31): one bit-field extract
+// instead of a 64-bit shift and a mask, three times per item.
+template <int SRC, bool OWNER, int KCLASS, int KFIX = 0, bool BINLO = false>
 __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, const qh_geom g) {
   const int K = KFIX ? KFIX : g.k;
+  auto bin_of_item = [&](uint64_t item) -> uint32_t {  // item = hash << 1 | q
+    return BINLO ? __builtin_amdgcn_ubfe((uint32_t)item, (uint32_t)p.bin_shift + 1u, p.bin_bits)
+                 : (uint32_t)((item >> 1) >> p.bin_shift) & p.bin_mask;
+  };
   __shared__ uint64_t sorted[QP_TILE_ITEMS];
   __shared__ uint32_t cursor[QP_MAX_BINS];  // histogram, then running placement cursor
   __shared__ uint32_t offs[QP_MAX_BINS];    // exclusive prefix of the histogram
@@ -311,7 +318,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
             } else {
               ++n_inst; n_hq += q;
               it[j] = (h << 1) | q;
-              atomicAdd(&cursor[(uint32_t)(h >> p.bin_shift) & p.bin_mask], 1u);
+              atomicAdd(&cursor[bin_of_item(it[j])], 1u);
             }
           }
         }
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
           } else {
             ++n_inst; n_hq += q;
             it[i] = (h << 1) | q;
-            atomicAdd(&cursor[(uint32_t)(h >> p.bin_shift) & p.bin_mask], 1u);
+            atomicAdd(&cursor[bin_of_item(it[i])], 1u);
           }
         }
       }
@@ -386,8 +393,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
 #pragma unroll
     for (int i = 0; i < QP_BLOCKS_PER_WAVE; ++i) {
       if (it[i] != QP_NONE) {
-        const uint32_t b = (uint32_t)((it[i] >> 1) >> p.bin_shift) & p.bin_mask;
-        sorted[atomicAdd(&cursor[b], 1u)] = it[i];
+        sorted[atomicAdd(&cursor[bin_of_item(it[i])], 1u)] = it[i];
       }
     }
 #pragma unroll
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
     const uint32_t total = s_total;
     for (uint32_t j = tid; j < total; j += QP_THREADS) {
       const uint64_t v = sorted[j];
-      const uint32_t b = (uint32_t)((v >> 1) >> p.bin_shift) & p.bin_mask;
+      const uint32_t b = bin_of_item(v);
       const uint64_t dst = (uint64_t)gbase[b] + (j - offs[b]);
       if (dst < p.out_cap) {
         uint64_t* at = &p.out[(((uint64_t)in_bucket << p.out_bin_shift) | b) * p.out_cap + dst];
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
 static void fill_common(qp_params& p, const qh_part_dst& d, qh_meta* meta, int check_owner, int count_instances) {
   p.out = d.out; p.out_cap = d.out_cap; p.out_counts = d.out_counts;
   p.out_count_stride = d.out_count_stride ? d.out_count_stride : 1;
-  p.bin_shift = d.bin_shift; p.bin_mask = (1u << d.bin_bits) - 1; p.out_bin_shift = d.out_bin_shift;
+  p.bin_shift = d.bin_shift; p.bin_mask = (1u << d.bin_bits) - 1; p.bin_bits = (uint32_t)d.bin_bits; p.out_bin_shift = d.out_bin_shift;
   p.spill = d.spill; p.spill_cap = d.spill_cap; p.meta = meta;
   p.check_owner = check_owner; p.count_instances = count_instances;
 }
@@ -441,8 +447,13 @@ void qh_launch_partition_fastq(const qh_fastq_aux& a, uint32_t rec_cap, qh_meta*
   const int kclass = g.k < 4 ? 2 : g.k < QP_SEG ? 1 : 0;
 #define QP_LAUNCH_FASTQ(OWNER, KC, KF) hipLaunchKernelGGL((k_partition<QP_SRC_FASTQ, OWNER, KC, KF>), grid, block, 0, s, p, g)
   static const char* nofix = getenv("QH_NO_KFIX");  // A/B tests
+  static const char* nobinlo = getenv("QH_NO_BINLO");
   const int kfix = nofix ? 0 : g.k;
-  if (check_owner) {
+  const bool binlo = !nobinlo && d.bin_shift + d.bin_bits <= 31;
+  if (!check_owner && kclass == 0 && binlo) {  // the unsharded build of ordinary mer lengths
+    if (kfix == 24) hipLaunchKernelGGL((k_partition<QP_SRC_FASTQ, false, 0, 24, true>), grid, block, 0, s, p, g);
+    else hipLaunchKernelGGL((k_partition<QP_SRC_FASTQ, false, 0, 0, true>), grid, block, 0, s, p, g);
+  } else if (check_owner) {
     if (kclass == 2) QP_LAUNCH_FASTQ(true, 2, 0);
     else if (kclass == 1) QP_LAUNCH_FASTQ(true, 1, 0);
     else if (kfix == 24) QP_LAUNCH_FASTQ(true, 0, 24);
@@ -469,7 +480,10 @@ void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsign
   uint64_t gx = n_in_buckets >= 256 ? 1 : (256 + n_in_buckets - 1) / n_in_buckets * 2;
   if (gx > tiles) gx = tiles;
   const dim3 grid((unsigned)gx, n_in_buckets), block(QP_THREADS);
+  static const char* nobinlo = getenv("QH_NO_BINLO");
+  const bool binlo = !nobinlo && d.bin_shift + d.bin_bits <= 31;
   if (check_owner) hipLaunchKernelGGL((k_partition<QP_SRC_ITEMS, true, 0>), grid, block, 0, s, p, g);
+  else if (binlo) hipLaunchKernelGGL((k_partition<QP_SRC_ITEMS, false, 0, 0, true>), grid, block, 0, s, p, g);
   else hipLaunchKernelGGL((k_partition<QP_SRC_ITEMS, false, 0>), grid, block, 0, s, p, g);
 }
 
