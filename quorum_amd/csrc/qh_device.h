@@ -254,7 +254,10 @@ __device__ __forceinline__ uint64_t qh_hash_strands_form(uint32_t m0, uint32_t m
   // the strand with the smaller core supplies it; equal cores: the key's own strand (no flip)
   const bool cfwd = (ltc > (dc ^ ltc)) | ((dc == 0) & fwd);
   const uint32_t cL = ((cfwd ? m0 : r0) >> 1) & cm, cR = ((cfwd ? m1 : r1) >> 1) & cm;
-  const uint32_t e = (c0 & 1u) | ((c1 & 1u) << 1) | ((c0 >> (k - 1)) << 2) | ((c1 >> (k - 1)) << 3);
+  // e = c0 bit 0 | c1 bit 0 << 1 | c0 bit k-1 << 2 | c1 bit k-1 << 3 (qh_mix_pair), the two planes' end bits gathered together
+  const uint32_t em = 1u | (1u << (k - 1));
+  const uint32_t u = (c0 & em) | ((c1 & em) << 1);
+  const uint32_t e = (u & 3u) | ((u >> (k - 3)) & 12u);
   return (qh_feistel3(cL, cR, kc) ^ QH_MIX_Z) | ((uint64_t)(e | ((uint32_t)(fwd != cfwd) << 4)) << (2 * kc));
 }
 

@@ -285,9 +285,14 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
     __syncthreads();
 
     // ---- pass 1: produce this wave's items (kept in registers) and the tile histogram
+    // FASTQ source: bit i of live = it[i] holds an item of this shard; item source: QP_NONE marks the others
+    // (measured: the mask costs level 2 4 %, the sentinel's initialisation costs level 1 its 12 moves)
     uint64_t it[QP_BLOCKS_PER_WAVE];
+    uint32_t live = 0;
+    if (SRC == QP_SRC_ITEMS) {
 #pragma unroll
-    for (int i = 0; i < QP_BLOCKS_PER_WAVE; ++i) it[i] = QP_NONE;
+      for (int i = 0; i < QP_BLOCKS_PER_WAVE; ++i) it[i] = QP_NONE;
+    }
 
     if (SRC == QP_SRC_FASTQ) {
       // create_database.cc:64-92 for the segment's k-mers: no rolling registers, every k-mer is a
@@ -302,21 +307,31 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
         };
         // bases past the segment's last k-mer count as no bases: the windows past its count are then invalid
         const uint64_t wv = fun(pl[0], o) & ((1ull << (cnt + K - 1)) - 1), w0 = fun(pl[1], o), w1 = fun(pl[2], o), wh = fun(pl[3], oq);
+        // low_len >= k (:85) and high_len >= k (:86) for the segment's windows at once: bit j of runs(x) = bits
+        // j .. j+K-1 of x are all ones (log-step ANDs), instead of a mask-and-compare per window and plane
+        auto runs = [&](uint64_t x) -> uint32_t {
+          int have = 1;
+          while (have * 2 <= K) { x &= x >> have; have *= 2; }
+          if (have < K) x &= x >> (K - have);
+          return (uint32_t)x & ((1u << QP_SEG) - 1u);
+        };
+        const uint32_t vm = runs(wv), hm = runs(wh) & vm;
+        if (!OWNER) { n_inst += __popc(vm); n_hq += __popc(hm); live = vm; }
         // forward orientation: bit-reversed planes, aligned so that the newest base of k-mer j sits
         // at bit QP_SEG-1-j
         const int sh0 = 64 - K - (QP_SEG - 1);
         const uint64_t f0 = __builtin_bitreverse64(w0) >> sh0, f1 = __builtin_bitreverse64(w1) >> sh0;
 #pragma unroll
         for (int j = 0; j < QP_SEG; ++j) {
-          if (((uint32_t)(wv >> j) & kones) == kones) {  // low_len >= k (:85), and j < cnt
-            const uint32_t q = ((uint32_t)(wh >> j) & kones) == kones;         // high_len >= k (:86)
+          if ((vm >> j) & 1u) {
+            const uint32_t q = (hm >> j) & 1u;
             const uint32_t r0 = ~(uint32_t)(w0 >> j) & kones, r1 = ~(uint32_t)(w1 >> j) & kones;
             const uint32_t m0 = (uint32_t)(f0 >> (QP_SEG - 1 - j)) & kones, m1 = (uint32_t)(f1 >> (QP_SEG - 1 - j)) & kones;
             const uint64_t h = qh_hash_strands_form<KCLASS == 2>(m0, m1, r0, r1, K);  // min(m, rm) of create_database.cc:86, hashed
             if (OWNER && ((uint32_t)h & smask) != (uint32_t)g.shard_id) {
               ++n_foreign;
             } else {
-              ++n_inst; n_hq += q;
+              if (OWNER) { ++n_inst; n_hq += q; live |= 1u << j; }
               it[j] = (h << 1) | q;
               atomicAdd(&cursor[bin_of_item(it[j])], 1u);
             }
@@ -392,7 +407,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
     // ---- pass 2: place the items bucket-sorted into LDS
 #pragma unroll
     for (int i = 0; i < QP_BLOCKS_PER_WAVE; ++i) {
-      if (it[i] != QP_NONE) {
+      if (SRC == QP_SRC_ITEMS ? it[i] != QP_NONE : ((live >> i) & 1u) != 0) {
         sorted[atomicAdd(&cursor[bin_of_item(it[i])], 1u)] = it[i];
       }
     }
