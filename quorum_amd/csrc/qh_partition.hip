@@ -202,7 +202,7 @@ __device__ __forceinline__ void qp_spill(const qp_params& p, uint64_t item) {
 // OWNER: items are checked against the shard that owns them (p.check_owner); KCLASS: 2 is k < 4 (no core in the
 // hash; 0 and 1 are compiled alike). Both are the same for
 // every item of a launch, and the extraction loop is bound by the instructions it issues per k-mer.
-// KFIX: the mer length when it is known at compile time (24 = the quorum driver's default, 31), else 0: shift counts
+// KFIX: the mer length when it is known at compile time (24 = the quorum driver's default, 31 = the largest), else 0: shift counts
 // and masks of the extraction loop fold into the instructions.
 // BINLO: the bin field of (hash << 1 | q) lies in the low 32 bits (bin_shift + bin_bits <= 31): one bit-field extract
 // instead of a 64-bit shift and a mask, three times per item.
@@ -300,7 +300,8 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
       // from the sequence bytes, h from the quality bytes.
       const uint32_t o = sd_cur.x & 63u, oq = (sd_cur.x + (sd_cur.y >> 4)) & 63u, cnt = sd_cur.y & 15u;
       if (cnt) {
-        const uint32_t kones = (uint32_t)((1ull << K) - 1);
+        // (k = 31: the mask comes from the geometry; as a literal, 2^31 - 1 crashes the instruction selection of clang 22)
+        const uint32_t kones = KFIX == 31 ? (uint32_t)((1ull << g.k) - 1) : (uint32_t)((1ull << K) - 1);
         auto fun = [&](const uint4& w2, uint32_t sh) -> uint64_t {
           const uint64_t lo = ((uint64_t)w2.y << 32) | w2.x, hi = ((uint64_t)w2.w << 32) | w2.z;
           return (lo >> sh) | ((hi << 1) << (63 - sh));
@@ -467,16 +468,19 @@ void qh_launch_partition_fastq(const qh_fastq_aux& a, uint32_t rec_cap, qh_meta*
   const bool binlo = !nobinlo && d.bin_shift + d.bin_bits <= 31;
   if (!check_owner && kclass == 0 && binlo) {  // the unsharded build of ordinary mer lengths
     if (kfix == 24) hipLaunchKernelGGL((k_partition<QP_SRC_FASTQ, false, 0, 24, true>), grid, block, 0, s, p, g);
+    else if (kfix == 31) hipLaunchKernelGGL((k_partition<QP_SRC_FASTQ, false, 0, 31, true>), grid, block, 0, s, p, g);
     else hipLaunchKernelGGL((k_partition<QP_SRC_FASTQ, false, 0, 0, true>), grid, block, 0, s, p, g);
   } else if (check_owner) {
     if (kclass == 2) QP_LAUNCH_FASTQ(true, 2, 0);
     else if (kclass == 1) QP_LAUNCH_FASTQ(true, 1, 0);
     else if (kfix == 24) QP_LAUNCH_FASTQ(true, 0, 24);
+    else if (kfix == 31) QP_LAUNCH_FASTQ(true, 0, 31);
     else QP_LAUNCH_FASTQ(true, 0, 0);
   } else {
     if (kclass == 2) QP_LAUNCH_FASTQ(false, 2, 0);
     else if (kclass == 1) QP_LAUNCH_FASTQ(false, 1, 0);
     else if (kfix == 24) QP_LAUNCH_FASTQ(false, 0, 24);
+    else if (kfix == 31) QP_LAUNCH_FASTQ(false, 0, 31);
     else QP_LAUNCH_FASTQ(false, 0, 0);
   }
 #undef QP_LAUNCH_FASTQ
