@@ -39,8 +39,10 @@ def build(data, k, bits, size, mode, level1_bits=-1, chunks=1, thresh=38, **kw):
     return h, st, m, v
 
 
+# (1 << 24, 10, 2): 1024 level-1 bins in front of a second level, as the 2^32-slot tables have
 @pytest.mark.parametrize("size,level1_bits,chunks", [(1 << 14, -1, 1), (1 << 16, -1, 1), (1 << 20, -1, 3),
-                                                     (1 << 20, 3, 1), (1 << 22, 4, 2), (1 << 22, 0, 1)])
+                                                     (1 << 20, 3, 1), (1 << 22, 4, 2), (1 << 22, 0, 1),
+                                                     (1 << 24, 10, 2)])
 @pytest.mark.parametrize("k,bits", [(24, 7), (31, 3), (9, 5)])
 def test_partitioned_matches_oracle(size, level1_bits, chunks, k, bits):
     rng = np.random.default_rng(size % 1000 + k)
