@@ -7,7 +7,7 @@ import quorum_amd as qa
 from quorum_amd import synth
 
 rows = []
-for k, L, reads, size, bits in [(24, 100, 2_000_000, 50_000_000, 7), (31, 150, 1_500_000, 200_000_000, 7),
+for k, L, reads, size, bits in [] if "--only-big" in sys.argv else [(24, 100, 2_000_000, 50_000_000, 7), (31, 150, 1_500_000, 200_000_000, 7),
                                 (31, 150, 1_500_000, 60_000_000, 7), (17, 250, 800_000, 50_000_000, 4),
                                 (24, 100, 8_000_000, 200_000_000, 7)]:
     g = synth.make_genome(5_000_000 if reads <= 2_000_000 else 20_000_000)
