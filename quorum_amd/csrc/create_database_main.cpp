@@ -339,6 +339,16 @@ int main(int argc, char* argv[]) {
   auto secs = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
   const char* cb = getenv("QUORUM_HIP_CHUNK_MB");
   size_t chunk = (cb && atol(cb) > 0 ? (size_t)atol(cb) : 256) << 20;
+  if (!(cb && atol(cb) > 0)) {
+    // A chunk that goes through the partitioned build streams every window of the table once: the chunk should bring
+    // a GPU about half as many k-mers as its table has slots (about 0.4 k-mers per byte of FASTQ), within the 4 GB a
+    // chunk may have. 2^26 slots stay at 256 MiB; the 2^32-slot table of a human genome reads 3.75 GiB at a time.
+    uint64_t slots = 1;
+    while (slots < args.size && slots < (1ull << 62)) slots <<= 1;
+    const uint64_t per_gpu = slots / (uint64_t)args.gpus, want = per_gpu + per_gpu / 4;
+    const uint64_t most = (uint64_t)3840 << 20;
+    if (want > chunk) chunk = (size_t)(want < most ? want : most);
+  }
   if (args.gpus > 1) {  // the table hash-sharded over several GPUs, one process (src/create_database.cc:117-125)
     qh_multi* m = nullptr;
     int mrc = qh_multi_create(&m, (int)args.mer, (int)args.bits, args.size, (int)qual_thresh, args.reprobe, args.gpus,
