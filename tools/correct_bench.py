@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="reads the oracle corrects for the CPU baseline (0 = skip)")
+    ap.add_argument("--err", type=float, default=0.01, help="substitution rate of the reads (0: the kernel's straight path only)")
+    ap.add_argument("--db-err", type=float, default=-1, help="substitution rate of the reads the database is built from (default: the corrected reads themselves)")
     ap.add_argument("--fetch", action="store_true", help="also time the copy of both text streams to the host")
     args = ap.parse_args()
 
@@ -42,11 +44,16 @@ def main():
     from quorum_amd._lib import lib, check
 
     genome = synth.make_genome(args.genome, seed=42)
-    fq = synth.make_fastq(genome, args.reads, READ_LEN, err=0.01, n_rate=0.0005, seed=42)
+    fq = synth.make_fastq(genome, args.reads, READ_LEN, err=args.err, n_rate=0.0005 if args.err else 0.0, seed=42)
     chunk = torch.from_numpy(fq).cuda()
     torch.cuda.synchronize()
     h = qa.HashWithQuality(args.size, 2 * K, BITS, min_qual=MIN_QUAL)
-    h.add_fastq_device(chunk.data_ptr(), chunk.numel())
+    if args.db_err >= 0:
+        dbchunk = torch.from_numpy(synth.make_fastq(genome, args.reads, READ_LEN, err=args.db_err, n_rate=0.0005, seed=42)).cuda()
+        torch.cuda.synchronize()
+        h.add_fastq_device(dbchunk.data_ptr(), dbchunk.numel())
+    else:
+        h.add_fastq_device(chunk.data_ptr(), chunk.numel())
     st_build = h.done()
     q = h.as_query()
     ec = qa.ErrorCorrector(q)
