@@ -380,7 +380,9 @@ typedef struct qh_corrector qh_corrector; /* ~ error_correct_t + its error_corre
 
 /* error_correct_t set up as in main (src/error_correct_reads.cc:720-736) over an open
  * database and an optional contaminant set (NULL = contaminant_no_database, :75-81; same k
- * and device as db, :703-705). Both handles must outlive the corrector. */
+ * and device as db, :703-705). Both handles must outlive the corrector. The corrector may keep a
+ * private copy of the database re-hashed to a lower load for its walks (QH_EC_TABLE_LOAD, default 0.3,
+ * 0 = never; only when the copy takes less than a quarter of the free device memory). */
 int qh_corrector_create(qh_corrector** out, qh_query* db, qh_query* contaminant, const qh_correct_params* p);
 void qh_corrector_destroy(qh_corrector* c);
 

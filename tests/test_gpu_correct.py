@@ -84,6 +84,19 @@ def test_default_switches(bacterial, via):
     assert st["corrected"] > 11000 and st["substitutions"] > 5000
 
 
+@pytest.mark.parametrize("load", ["0", "0.3", "0.05"])
+def test_sparser_private_table(bacterial, load, monkeypatch):
+    """a database at load 0.41: the corrector re-hashes it into a table of load <= QH_EC_TABLE_LOAD for its walks (0: works
+    on the database's own table; 0.05: three doublings) -- the text is the oracle's either way"""
+    g, fq, _, _ = bacterial
+    odb, h, q = build_pair(fq, 24, size=1 << 19)
+    assert odb.distinct() > 0.4 * (1 << 19) and h.stats()["slots"] == 1 << 19
+    monkeypatch.setenv("QH_EC_TABLE_LOAD", load)
+    check_parity(odb, q, fq, via="device")
+    assert (q.lookup(np.arange(1000, dtype=np.uint64)) == odb.lookup(np.arange(1000, dtype=np.uint64))).all()  # the handle is untouched
+    q.close(); h.close(); odb.close()
+
+
 @pytest.mark.parametrize("kw", [
     dict(window=0, error=0),                     # window = k, error = k / 2 (error_correct_reads.cc:206-207)
     dict(skip=0, good=1, anchor_count=1),
