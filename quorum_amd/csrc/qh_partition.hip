@@ -83,7 +83,9 @@ __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t* __restrict__ v, uin
 __global__ __launch_bounds__(256) void k_rec_segs_apply(const uint4* __restrict__ recs, qh_meta* __restrict__ meta,
                                                         const uint32_t* __restrict__ tile_sums, uint32_t k,
                                                         uint2* __restrict__ seg_desc) {
+  constexpr uint32_t SEG_STAGE = 3072;  // 256 reads of 100 to 150 bases make 1800 to 3100 segments
   __shared__ uint32_t wtot[4];
+  __shared__ uint2 stage[SEG_STAGE];
   const uint32_t nrec = meta->format_err ? 0 : meta->nrec;
   const uint32_t base = blockIdx.x * RB_TILE;
   if (base >= nrec) return;
@@ -108,9 +110,12 @@ __global__ __launch_bounds__(256) void k_rec_segs_apply(const uint4* __restrict_
       if (w < wv) swbase += y;
       stot += y;
     }
+    // the descriptors of these 256 records are consecutive: staged in LDS and written as one run (a thread's own
+    // stores lie 8 * cs bytes apart from its neighbour's); reads of thousands of bases write where they belong
+    const bool staged = stot <= SEG_STAGE;
     if (cs) {
       // k-mers [a, a + n) of the read; k-mer i spans bases i .. i+k-1
-      const uint32_t ps = srun + swbase + sinc - cs, nk = rc.y - k + 1;
+      const uint32_t ps = swbase + sinc - cs, nk = rc.y - k + 1;
       uint32_t dist = rc.z - rc.x;  // bases, newline, separator line, newline
       if (dist >> 28) {             // a line of 256 MiB
         atomicOr(&meta->format_err, QH_FMT_LINE_TOO_LONG);
@@ -122,9 +127,14 @@ __global__ __launch_bounds__(256) void k_rec_segs_apply(const uint4* __restrict_
       const uint32_t each = nk / cs, more = nk - each * cs;
       for (uint32_t b = 0; b < cs; ++b) {
         const uint32_t a = b * each + (b < more ? b : more);
-        seg_desc[ps + b] = make_uint2(rc.x + a, (dist << 4) | (each + (b < more ? 1u : 0u)));
+        const uint2 d = make_uint2(rc.x + a, (dist << 4) | (each + (b < more ? 1u : 0u)));
+        if (staged) stage[ps + b] = d;
+        else seg_desc[srun + ps + b] = d;
       }
     }
+    __syncthreads();
+    if (staged)
+      for (uint32_t i = threadIdx.x; i < stot; i += 256) seg_desc[srun + i] = stage[i];
     srun += stot;
     __syncthreads();
   }
