@@ -481,7 +481,7 @@ extern "C" int qh_build_add_fastq_device(qh_build* h, const void* dev_buf, size_
   const size_t rec_cap = len / 16 + 16;
   if ((rc = ensure((void**)&h->d_tiles, &h->tile_cap, (ntiles + 1) * 4, "tile counts"))) return rc;
   if ((rc = ensure((void**)&h->d_recs, &h->rec_cap, rec_cap * 16, "record table"))) return rc;
-  if ((rc = ensure((void**)&h->d_nlplane, &h->nlplane_cap, (len / 16 + 2) * 8, "newline plane"))) return rc;
+  if ((rc = ensure((void**)&h->d_nlplane, &h->nlplane_cap, (len / 16 + 2) * 8 + 8192, "newline lists"))) return rc;
   const bool part = use_partition(h, len / 2);
   qh_fastq_aux aux;
   if (part && (rc = fastq_aux(h, len, rec_cap, len / 2, &aux))) return rc;
@@ -823,7 +823,7 @@ extern "C" int qh_build_extract_partitioned_device(qh_build* h, const void* dev_
   const size_t rec_cap = len / 16 + 16;
   if ((rc = ensure((void**)&h->d_tiles, &h->tile_cap, (ntiles + 1) * 4, "tile counts"))) return rc;
   if ((rc = ensure((void**)&h->d_recs, &h->rec_cap, rec_cap * 16, "record table"))) return rc;
-  if ((rc = ensure((void**)&h->d_nlplane, &h->nlplane_cap, (len / 16 + 2) * 8, "newline plane"))) return rc;
+  if ((rc = ensure((void**)&h->d_nlplane, &h->nlplane_cap, (len / 16 + 2) * 8 + 8192, "newline lists"))) return rc;
   qh_fastq_aux aux;
   if ((rc = fastq_aux(h, len, rec_cap, len / 2, &aux))) return rc;
   qh_launch_index_fastq((const uint8_t*)dev_buf, len, h->d_tiles, h->d_nlplane, h->d_recs, (uint32_t)rec_cap, h->d_meta,

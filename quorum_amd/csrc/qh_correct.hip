@@ -1302,7 +1302,7 @@ static int correct_device_on(qh_corrector* c, const void* dev_buf, size_t len) {
   const size_t rec_cap = len / 16 + 16;
   if ((rc = ensure_dev((void**)&c->d_tiles, &c->tile_cap, (ntiles + 1) * 4, "tile counts"))) return rc;
   if ((rc = ensure_dev((void**)&c->d_recs, &c->rec_cap, rec_cap * 16, "record table"))) return rc;
-  if ((rc = ensure_dev((void**)&c->d_nlplane, &c->nlplane_cap, (len / 16 + 2) * 8, "newline plane"))) return rc;
+  if ((rc = ensure_dev((void**)&c->d_nlplane, &c->nlplane_cap, (len / 16 + 2) * 8 + 8192, "newline lists"))) return rc;
   QH_HIP(hipEventRecord(c->ev[0], c->stream));
   QH_HIP(hipMemsetAsync(c->d_meta, 0, sizeof(qh_meta), c->stream));
   qh_launch_index_fastq((const uint8_t*)dev_buf, len, c->d_tiles, c->d_nlplane, c->d_recs, (uint32_t)rec_cap, c->d_meta,

@@ -30,7 +30,7 @@ enum { QH_FMT_LINES_MOD4 = 1, QH_FMT_NO_AT = 2, QH_FMT_NO_PLUS = 4, QH_FMT_LEN_M
 
 // --- FASTQ chunk -> record table -------------------------------------------------
 // rec_cap = capacity of `recs` in records. tile_counts has ceil(len/QH_TILE_BYTES)+1 entries,
-// nl_plane ceil(len/16) entries {newline mask, ...followed by '@', ...followed by '+', 0} of 16 bytes each. planes != null: also fill the text planes of qh_fastq_aux
+// nl_plane: room for the tiles' newline lists, 4096 16-bit entries a tile = (len/16 + 2) * 8 + 8192 bytes. planes != null: also fill the text planes of qh_fastq_aux
 // (same pass over the text).
 void qh_launch_index_fastq(const uint8_t* buf, size_t len, uint32_t* tile_counts, ushort4* nl_plane, uint4* recs,
                            uint32_t rec_cap, qh_meta* meta, const struct qh_fastq_aux* planes, int min_qual,

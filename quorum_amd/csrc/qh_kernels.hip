@@ -17,45 +17,95 @@
 
 // ------------------------------------------------------- FASTQ chunk -> record table
 
-// pass 1, the only pass over the chunk's text: newlines per 16 KiB tile, the newline plane (one
-// bit per byte, 16 bits per lane) that pass 3 works from, and -- when the chunk goes through the
-// partitioned build -- the four text planes of qh_partition.hip
+// pass 1, the only pass over the chunk's text: newlines per 16 KiB tile, the tile's newlines as a compact list for
+// pass 3 -- one 16-bit entry each: {byte position inside the tile : 14 | the next byte is '@' : 1 | is '+' : 1}, in
+// text order, QH_NL_CAP to a tile -- and, when the chunk goes through the partitioned build, the four text planes of
+// qh_partition.hip. (Round 1 wrote a dense plane of newline bits, 8 bytes per 16 bytes of text whether they held a
+// newline or not: 0.22 GB written here and read back by pass 3 for the 16 MB of entries they carried.)
+#define QH_NL_CAP 4096u  // more newlines in 16 KiB: lines of under 4 bytes, records the fast path rejects anyway
 __global__ __launch_bounds__(QH_BLOCK) void k_index_text(const uint8_t* __restrict__ buf, size_t len,
                                                          uint32_t* __restrict__ tile_counts,
-                                                         ushort4* __restrict__ nl_plane,
+                                                         uint16_t* __restrict__ nl_list,
                                                          uint16_t* __restrict__ planes, size_t plane_halfwords,
-                                                         int min_qual) {
+                                                         int min_qual, qh_meta* __restrict__ meta) {
+  constexpr uint32_t UNITS = QH_TILE_BYTES / 16;  // 1024: unit j * 256 + t is thread t's j-th
+  __shared__ uint32_t ucnt[UNITS];   // newlines per unit, then their exclusive prefix in text order
+  __shared__ uint16_t stage[QH_NL_CAP];
   __shared__ uint32_t wsum[QH_BLOCK / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const size_t tile_base = (size_t)blockIdx.x * QH_TILE_BYTES;
   const qh_swar_thr thr = qh_swar_threshold(min_qual);
-  uint32_t cnt = 0;
+  uint32_t m[4], m_at[4], m_plus[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const size_t off = tile_base + ((size_t)j * QH_BLOCK + threadIdx.x) * 16;
+    const uint32_t u = (uint32_t)j * QH_BLOCK + tid;
+    const size_t off = tile_base + (size_t)u * 16;
+    m[j] = 0; m_at[j] = 0; m_plus[j] = 0;
     if (off < len) {
       const uint4 x = load16_guarded(buf, off, len);
-      const uint32_t m = nl_mask16(x);
-      cnt += __popc(m);
+      m[j] = nl_mask16(x);
       // what follows each newline: '@' (a header must) or '+' (a separator must); pass 3 knows which
       const uint32_t w[5] = {x.x, x.y, x.z, x.w, off + 16 < len ? (uint32_t)buf[off + 16] : 0u};
-      uint32_t mm = m, m_at = 0, m_plus = 0;
+      uint32_t mm = m[j];
       while (mm) {
         const int b = __ffs(mm) - 1;
         mm &= mm - 1;
         const int nb = b + 1, ws = nb >> 2;
         const uint32_t d = ws == 0 ? w[0] : ws == 1 ? w[1] : ws == 2 ? w[2] : ws == 3 ? w[3] : w[4];
         const uint32_t c = (d >> (8 * (nb & 3))) & 0xFFu;
-        m_at |= (uint32_t)(c == '@') << b;
-        m_plus |= (uint32_t)(c == '+') << b;
+        m_at[j] |= (uint32_t)(c == '@') << b;
+        m_plus[j] |= (uint32_t)(c == '+') << b;
       }
-      nl_plane[off >> 4] = make_ushort4((unsigned short)m, (unsigned short)m_at, (unsigned short)m_plus, 0);
       if (planes) qh_store_text_planes(x, off >> 4, planes, plane_halfwords, thr);
     }
+    ucnt[u] = __popc(m[j]);
   }
-  cnt = wave_sum_u32(cnt);
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
   __syncthreads();
-  if (threadIdx.x == 0) tile_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  // exclusive prefix of the units' counts in text order: thread t scans units 4t .. 4t+3 (measured: prefix sums by
+  // shuffles over a (wave, j, lane) layout instead of this pass through LDS cost the step 0.02 ms)
+  uint32_t c4[4], cs = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { c4[i] = ucnt[4 * tid + i]; cs += c4[i]; }
+  uint32_t inc = cs;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += v;
+  }
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  uint32_t wbase = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < QH_BLOCK / 64; ++w) {
+    if (w < wv) wbase += wsum[w];
+    tot += wsum[w];
+  }
+  {
+    uint32_t run = wbase + inc - cs;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ucnt[4 * tid + i] = run; run += c4[i]; }
+  }
+  if (tid == 0) {
+    tile_counts[blockIdx.x] = tot;
+    if (tot > QH_NL_CAP) { atomicOr(&meta->format_err, QH_FMT_TOO_MANY); atomicMin(&meta->first_bad, 0u); }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t u = (uint32_t)j * QH_BLOCK + tid;
+    uint32_t idx = ucnt[u], mm = m[j];
+    while (mm) {
+      const int b = __ffs(mm) - 1;
+      mm &= mm - 1;
+      if (idx < QH_NL_CAP)
+        stage[idx] = (uint16_t)((u * 16u + (uint32_t)b) | (((m_at[j] >> b) & 1u) << 14) | (((m_plus[j] >> b) & 1u) << 15));
+      ++idx;
+    }
+  }
+  __syncthreads();
+  const uint32_t nst = tot < QH_NL_CAP ? tot : QH_NL_CAP;
+  uint16_t* __restrict__ dst = nl_list + (size_t)blockIdx.x * QH_NL_CAP;
+  for (uint32_t i = tid; i < nst; i += QH_BLOCK) dst[i] = stage[i];
 }
 
 // pass 2: exclusive scan of the tile counts (one workgroup), chunk-level checks
@@ -71,6 +121,8 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ tile
     if (lines & 3u) err |= QH_FMT_LINES_MOD4;
     if ((lines >> 2) > rec_cap) err |= QH_FMT_TOO_MANY;
     if (len > 0 && buf[0] != '@') err |= QH_FMT_NO_AT;
+    err |= meta->format_err;  // pass 1: a tile with more newlines than its list holds
+    tile_counts[ntiles] = total_lines;  // pass 3 takes a tile's line count from the difference of two prefixes
     meta->n_lines = lines;
     meta->nrec = err ? 0 : (lines >> 2);
     meta->format_err = err;
@@ -92,62 +144,25 @@ __device__ __forceinline__ uint32_t line_end(size_t len, uint32_t L, uint32_t p,
 }
 
 // pass 3: every newline writes its field of the record table. The table, read as words, is indexed by the line
-// number, and a tile's lines are consecutive: the fields are staged in LDS and written as one contiguous run
-// (8 M scattered 4-byte stores per 2 M reads otherwise).
+// number, a tile's lines are consecutive and its list is in text order: entry i of tile t is line prefix[t] + i, the
+// loads and the stores are both contiguous runs.
 __global__ __launch_bounds__(QH_BLOCK) void k_fill_records(const uint8_t* __restrict__ buf, size_t len,
-                                                           const ushort4* __restrict__ nl_plane,
+                                                           const uint16_t* __restrict__ nl_list,
                                                            const uint32_t* __restrict__ tile_prefix,
                                                            uint32_t* __restrict__ recs, uint32_t rec_cap,
                                                            qh_meta* __restrict__ meta) {
-  __shared__ uint32_t wtot[QH_BLOCK / 64];
-  constexpr uint32_t FIELD_CAP = 2048;       // lines of a tile that are staged (lines of 8 bytes on average)
-  __shared__ uint32_t field[FIELD_CAP];
   if (meta->format_err & (QH_FMT_LINES_MOD4 | QH_FMT_TOO_MANY)) return;
-  static_assert(QH_TILE_BYTES == QH_BLOCK * 4 * 16, "a thread takes four consecutive 16-byte units of the tile");
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  // four consecutive units (64 bytes of text) per thread: one scan of the newline counts per tile
-  const size_t off0 = (size_t)blockIdx.x * QH_TILE_BYTES + (size_t)threadIdx.x * 64;
-  ushort4 nl[4];
-  uint32_t c = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    nl[j] = off0 + (size_t)j * 16 < len ? nl_plane[(off0 >> 4) + j] : make_ushort4(0, 0, 0, 0);
-    c += __popc((uint32_t)nl[j].x);
-  }
-  uint32_t inc = c;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    uint32_t v = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += v;
-  }
-  if (lane == 63) wtot[wv] = inc;
-  __syncthreads();
-  uint32_t wbase = 0, tot = 0;
-#pragma unroll
-  for (int w = 0; w < QH_BLOCK / 64; ++w) {
-    if (w < wv) wbase += wtot[w];
-    tot += wtot[w];
-  }
-  const uint32_t L0 = tile_prefix[blockIdx.x];
+  const uint32_t L0 = tile_prefix[blockIdx.x];  // (the scan leaves the total behind the last tile)
+  uint32_t n = tile_prefix[blockIdx.x + 1] - L0;
+  if (n > QH_NL_CAP) n = QH_NL_CAP;  // never past the tile's list (pass 1 has rejected such a chunk)
   const uint64_t words = (uint64_t)rec_cap * 4;
-  const bool staged = tot <= FIELD_CAP;  // else (lines of a few bytes) every field is written where it belongs
-  uint32_t idx = wbase + inc - c;  // of this thread's first newline among the tile's
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    uint32_t m = nl[j].x;
-    while (m) {
-      const int bpos = __ffs(m) - 1;
-      m &= m - 1;
-      const uint32_t f = line_end(len, L0 + idx, (uint32_t)(off0 + (size_t)j * 16 + bpos), (nl[j].y >> bpos) & 1, (nl[j].z >> bpos) & 1, meta);
-      if (staged) field[idx] = f;
-      else if ((uint64_t)L0 + idx < words) recs[(size_t)L0 + idx] = f;
-      ++idx;
-    }
+  const uint16_t* __restrict__ src = nl_list + (size_t)blockIdx.x * QH_NL_CAP;
+  const size_t tile_base = (size_t)blockIdx.x * QH_TILE_BYTES;
+  for (uint32_t i = threadIdx.x; i < n; i += QH_BLOCK) {
+    const uint32_t e = src[i];
+    const uint32_t f = line_end(len, L0 + i, (uint32_t)(tile_base + (e & 0x3FFFu)), (e >> 14) & 1u, (e >> 15) & 1u, meta);
+    if ((uint64_t)L0 + i < words) recs[(size_t)L0 + i] = f;
   }
-  __syncthreads();
-  if (staged)
-    for (uint32_t i = threadIdx.x; i < tot; i += QH_BLOCK)
-      if ((uint64_t)L0 + i < words) recs[(size_t)L0 + i] = field[i];
   if (blockIdx.x == 0 && threadIdx.x == 0 && len > 0 && buf[len - 1] != '\n') {
     const uint32_t L = meta->n_lines - 1;
     const uint32_t f = line_end(len, L, (uint32_t)len, true, true, meta);
@@ -176,13 +191,14 @@ void qh_launch_index_fastq(const uint8_t* buf, size_t len, uint32_t* tile_counts
                            uint32_t rec_cap, qh_meta* meta, const qh_fastq_aux* planes, int min_qual, hipStream_t s) {
   const uint32_t ntiles = (uint32_t)((len + QH_TILE_BYTES - 1) / QH_TILE_BYTES);
   if (ntiles)
-    hipLaunchKernelGGL(k_index_text, dim3(ntiles), dim3(QH_BLOCK), 0, s, buf, len, tile_counts, nl_plane,
+    hipLaunchKernelGGL(k_index_text, dim3(ntiles), dim3(QH_BLOCK), 0, s, buf, len, tile_counts,
+                       reinterpret_cast<uint16_t*>(nl_plane),
                        planes ? reinterpret_cast<uint16_t*>(planes->planes) : nullptr,
-                       planes ? (size_t)planes->plane_words * 4 : 0, min_qual);
+                       planes ? (size_t)planes->plane_words * 4 : 0, min_qual, meta);
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_counts, ntiles, buf, len, rec_cap, meta);
   if (ntiles)
-    hipLaunchKernelGGL(k_fill_records, dim3(ntiles), dim3(QH_BLOCK), 0, s, buf, len, nl_plane, tile_counts,
-                       reinterpret_cast<uint32_t*>(recs), rec_cap, meta);
+    hipLaunchKernelGGL(k_fill_records, dim3(ntiles), dim3(QH_BLOCK), 0, s, buf, len,
+                       reinterpret_cast<const uint16_t*>(nl_plane), tile_counts, reinterpret_cast<uint32_t*>(recs), rec_cap, meta);
   hipLaunchKernelGGL(k_validate_records, dim3(1024), dim3(QH_BLOCK), 0, s, recs, meta);
 }
 
