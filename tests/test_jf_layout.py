@@ -122,3 +122,20 @@ def test_grows_when_reprobe_limit_is_hit(tmp_path):
     md.jf_write_file(path, k, bits, 1024, mers, vals, reprobe_limit=2)  # 98 % load, 3 probes: cannot fit
     _, _, size2, m2, v2 = md.jf_read_file(path)
     assert size2 > 1024 and dict(zip(m2.tolist(), v2.tolist())) == dict(zip(mers.tolist(), vals.tolist()))
+
+
+def test_host_module_under_sanitizers(tmp_path):
+    """the module's C++ (bit packing, GF(2) inverse, file reader) built with g++ -fsanitize=address,undefined and run on the
+    CPU: round trips, growth, rejected inputs (tests/cpp/test_jflayout_host.cpp)"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "quorum_amd", "csrc")
+    exe = str(tmp_path / "jf_host")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe,
+           os.path.join(root, "tests", "cpp", "test_jflayout_host.cpp"), os.path.join(csrc, "qh_jflayout.cpp"),
+           os.path.join(csrc, "qh_dbfile.cpp")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", (r.stdout + r.stderr)[-3000:]
