@@ -166,6 +166,43 @@ __device__ __forceinline__ void qh_store_text_planes(const uint4& x, size_t u, u
   planes[3 * plane_halfwords + u] = (uint16_t)(ll >> 16);
 }
 
+// The same flags by table: what swar_byte_flags computes for a byte, plus bit 4 = the byte is a newline. 256 entries
+// in LDS, filled once per workgroup (qh_byte_flags_of); a dword of text is four ds_read_u8 instead of ~50 VALU
+// instructions, which is what bounds the one kernel that reads all of the text.
+__device__ __forceinline__ uint32_t qh_byte_flags_of(uint32_t c, int min_qual) {
+  const uint32_t u = c & 0xDFu;
+  const uint32_t code = u == 'A' ? 0u : u == 'C' ? 1u : u == 'G' ? 2u : u == 'T' ? 3u : 4u;
+  uint32_t f = code < 4u ? (1u | (code << 2)) : 0u;
+  if ((int)(int8_t)c >= (int)(int8_t)min_qual) f |= 2u;
+  if (c == '\n') f |= 16u;
+  return f;
+}
+__device__ __forceinline__ uint32_t qh_lut_flags4(const uint8_t* lut, uint32_t w) {
+  return (uint32_t)lut[w & 0xFFu] | ((uint32_t)lut[(w >> 8) & 0xFFu] << 8) | ((uint32_t)lut[(w >> 16) & 0xFFu] << 16) |
+         ((uint32_t)lut[w >> 24] << 24);
+}
+// flags of the unit's 16 bytes (four dwords from qh_lut_flags4) -> its 16 newline bits
+__device__ __forceinline__ uint32_t qh_nl_from_flags(const uint32_t (&f)[4]) {
+  uint32_t m = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t t = f[i] >> 4;
+    m |= ((t & 1u) | ((t >> 7) & 2u) | ((t >> 14) & 4u) | ((t >> 21) & 8u)) << (4 * i);
+  }
+  return m;
+}
+__device__ __forceinline__ void qh_store_text_planes_flags(const uint32_t (&f)[4], size_t u, uint16_t* __restrict__ planes,
+                                                           size_t plane_halfwords) {
+  const uint32_t g0 = swar_transpose8(f[0] & 0x0F0F0F0Fu, f[1] & 0x0F0F0F0Fu);
+  const uint32_t g1 = swar_transpose8(f[2] & 0x0F0F0F0Fu, f[3] & 0x0F0F0F0Fu);
+  const uint32_t vh = __builtin_amdgcn_perm(g1, g0, 0x05010400u);
+  const uint32_t ll = __builtin_amdgcn_perm(g1, g0, 0x07030602u);
+  planes[u] = (uint16_t)vh;
+  planes[plane_halfwords + u] = (uint16_t)(vh >> 16);
+  planes[2 * plane_halfwords + u] = (uint16_t)ll;
+  planes[3 * plane_halfwords + u] = (uint16_t)(ll >> 16);
+}
+
 // ---------------------------------------------------------------- slot insertion
 
 // hash_with_quality::add on the single-word slot table. Returns false when the

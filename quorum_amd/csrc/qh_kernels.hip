@@ -34,7 +34,10 @@ __global__ __launch_bounds__(QH_BLOCK) void k_index_text(const uint8_t* __restri
   __shared__ uint32_t wsum[QH_BLOCK / 64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const size_t tile_base = (size_t)blockIdx.x * QH_TILE_BYTES;
-  const qh_swar_thr thr = qh_swar_threshold(min_qual);
+  __shared__ uint8_t lut[256];  // flags of every byte value (QH_BLOCK == 256 threads fill it)
+  static_assert(QH_BLOCK == 256, "one table entry per thread");
+  lut[tid] = (uint8_t)qh_byte_flags_of((uint32_t)tid, min_qual);
+  __syncthreads();
   uint32_t m[4], m_at[4], m_plus[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -43,7 +46,8 @@ __global__ __launch_bounds__(QH_BLOCK) void k_index_text(const uint8_t* __restri
     m[j] = 0; m_at[j] = 0; m_plus[j] = 0;
     if (off < len) {
       const uint4 x = load16_guarded(buf, off, len);
-      m[j] = nl_mask16(x);
+      const uint32_t fl[4] = {qh_lut_flags4(lut, x.x), qh_lut_flags4(lut, x.y), qh_lut_flags4(lut, x.z), qh_lut_flags4(lut, x.w)};
+      m[j] = qh_nl_from_flags(fl);
       // what follows each newline: '@' (a header must) or '+' (a separator must); pass 3 knows which
       const uint32_t w[5] = {x.x, x.y, x.z, x.w, off + 16 < len ? (uint32_t)buf[off + 16] : 0u};
       uint32_t mm = m[j];
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(QH_BLOCK) void k_index_text(const uint8_t* __restri
         m_at[j] |= (uint32_t)(c == '@') << b;
         m_plus[j] |= (uint32_t)(c == '+') << b;
       }
-      if (planes) qh_store_text_planes(x, off >> 4, planes, plane_halfwords, thr);
+      if (planes) qh_store_text_planes_flags(fl, off >> 4, planes, plane_halfwords);
     }
     ucnt[u] = __popc(m[j]);
   }
