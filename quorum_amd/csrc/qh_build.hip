@@ -373,7 +373,7 @@ static bool use_partition(const qh_build* h, size_t max_items) {
 
 // device arrays of the FASTQ source for a chunk of buf_len bytes, at most rec_cap records / max_bases bases
 static int fastq_aux(qh_build* h, size_t buf_len, size_t rec_cap, size_t max_bases, qh_fastq_aux* a) {
-  const size_t segs = max_bases / QH_SEG_KMERS + rec_cap, plane_words = (buf_len + 63) / 64 + 2;
+  const size_t segs = max_bases / QH_SEG_KMERS + rec_cap, plane_words = (buf_len + 16383) / 16384 * 256 + 2;  // whole 16 KiB tiles (k_index_text stores a tile's planes in 16-byte pieces), even
   int rc;
   if ((rc = ensure((void**)&h->d_rbsums, &h->rbsums_cap, (rec_cap / 1024 + 4) * 4, "segment sums"))) return rc;
   if ((rc = ensure((void**)&h->d_segdesc, &h->segdesc_cap, (segs + 2) * 8, "segment descriptors"))) return rc;

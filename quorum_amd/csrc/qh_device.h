@@ -203,6 +203,18 @@ __device__ __forceinline__ void qh_store_text_planes_flags(const uint32_t (&f)[4
   planes[3 * plane_halfwords + u] = (uint16_t)(ll >> 16);
 }
 
+// the same into a tile's staging area: plane p of unit u (0..1023 inside the tile) at stage[p * 1024 + u]
+__device__ __forceinline__ void qh_stage_text_planes_flags(const uint32_t (&f)[4], uint32_t u, uint16_t* stage) {
+  const uint32_t g0 = swar_transpose8(f[0] & 0x0F0F0F0Fu, f[1] & 0x0F0F0F0Fu);
+  const uint32_t g1 = swar_transpose8(f[2] & 0x0F0F0F0Fu, f[3] & 0x0F0F0F0Fu);
+  const uint32_t vh = __builtin_amdgcn_perm(g1, g0, 0x05010400u);
+  const uint32_t ll = __builtin_amdgcn_perm(g1, g0, 0x07030602u);
+  stage[u] = (uint16_t)vh;
+  stage[1024 + u] = (uint16_t)(vh >> 16);
+  stage[2048 + u] = (uint16_t)ll;
+  stage[3072 + u] = (uint16_t)(ll >> 16);
+}
+
 // ---------------------------------------------------------------- slot insertion
 
 // hash_with_quality::add on the single-word slot table. Returns false when the

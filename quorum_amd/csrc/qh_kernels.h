@@ -77,7 +77,7 @@ struct qh_part_dst {
 //   tile_sums  ceil(rec_cap/1024) + 1 words     scan scratch; ends with the segment total
 //   seg_desc   max_segs x 8 B                    {first base offset, (distance to its quality) << 4 | k-mers}
 //   planes     4 planes x plane_words words      v, h, l0, l1: one bit per byte of the chunk;
-//                                                plane_words >= ceil(len / 64) + 2
+//                                                plane_words = 256 per 16 KiB tile of the chunk + 2 (even)
 #define QH_SEG_KMERS 12
 struct qh_fastq_aux {
   uint32_t* tile_sums;

@@ -30,7 +30,8 @@ __global__ __launch_bounds__(QH_BLOCK) void k_index_text(const uint8_t* __restri
                                                          int min_qual, qh_meta* __restrict__ meta) {
   constexpr uint32_t UNITS = QH_TILE_BYTES / 16;  // 1024: unit j * 256 + t is thread t's j-th
   __shared__ uint32_t ucnt[UNITS];   // newlines per unit, then their exclusive prefix in text order
-  __shared__ uint16_t stage[QH_NL_CAP];
+  __shared__ __attribute__((aligned(16))) uint16_t stage[QH_NL_CAP];  // the tile's planes (4 x 1024 halfwords), then its newline entries
+  static_assert(QH_NL_CAP == 4096, "stage holds four planes of a tile");
   __shared__ uint32_t wsum[QH_BLOCK / 64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const size_t tile_base = (size_t)blockIdx.x * QH_TILE_BYTES;
@@ -60,11 +61,24 @@ __global__ __launch_bounds__(QH_BLOCK) void k_index_text(const uint8_t* __restri
         m_at[j] |= (uint32_t)(c == '@') << b;
         m_plus[j] |= (uint32_t)(c == '+') << b;
       }
-      if (planes) qh_store_text_planes_flags(fl, off >> 4, planes, plane_halfwords);
+      if (planes) qh_stage_text_planes_flags(fl, u, stage);
+    } else if (planes) {
+      stage[u] = 0; stage[1024 + u] = 0; stage[2048 + u] = 0; stage[3072 + u] = 0;
     }
     ucnt[u] = __popc(m[j]);
   }
   __syncthreads();
+  if (planes) {
+    // the tile's planes leave in 16-byte pieces (2 per thread) instead of sixteen 2-byte stores per thread: plane p of the
+    // tile is 2 KiB in a row, 16-byte aligned (plane_halfwords is a multiple of 8, a tile 1024 halfwords)
+    const uint4* st4 = reinterpret_cast<const uint4*>(stage);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const uint32_t c = (uint32_t)r * QH_BLOCK + tid, p = c >> 7, w = c & 127u;
+      *reinterpret_cast<uint4*>(planes + (size_t)p * plane_halfwords + (size_t)blockIdx.x * 1024 + (size_t)w * 8) = st4[c];
+    }
+    __syncthreads();  // stage is reused for the newline entries
+  }
   // exclusive prefix of the units' counts in text order: thread t scans units 4t .. 4t+3 (measured: prefix sums by
   // shuffles over a (wave, j, lane) layout instead of this pass through LDS cost the step 0.02 ms)
   uint32_t c4[4], cs = 0;
