@@ -12,6 +12,6 @@ agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     agg[r["Kernel_Name"].split("(")[0][:30]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in agg.items():
-    if "partition" in k or "window" in k or "build" in k:
+    if "partition" in k or "window" in k or "build" in k or "index" in k or "fill" in k or "segs" in k:
         print(k, {c: round(sum(x)/len(x)/1e6,2) for c,x in v.items()})
 PY
