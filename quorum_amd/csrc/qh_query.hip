@@ -10,6 +10,7 @@
 #include <fcntl.h>
 #include <errno.h>
 #include <sys/stat.h>
+#include <thread>
 #include <vector>
 
 #include "qh_internal.h"
@@ -108,27 +109,63 @@ extern "C" int qh_query_open(qh_query** out, const char* path, int device) {
   if (rc) { close(fd); qh_query_close(q); return rc; }
   hipError_t e = hipMalloc((void**)&q->table, fh.key_bytes);
   if (e != hipSuccess) { close(fd); qh_query_close(q); return qh_fail(QH_ENOMEM, "cannot allocate %llu bytes of HBM for the table: %s", (unsigned long long)fh.key_bytes, hipGetErrorString(e)); }
-  // stream the keys image into HBM through a pinned staging buffer
+  // stream the keys image into HBM through two pinned staging pieces: piece i + 1 is read from the file (by a few
+  // threads at once: the page-cache copy is what takes the time) while piece i travels to the device
   const size_t piece = (size_t)64 << 20;
-  void* stage = nullptr;
-  e = hipHostMalloc(&stage, piece, hipHostMallocDefault);
-  if (e != hipSuccess) { close(fd); qh_query_close(q); return qh_fail(QH_ENOMEM, "cannot allocate the staging buffer"); }
-  rc = QH_OK;
-  for (uint64_t at = 0; at < fh.key_bytes && rc == QH_OK; at += piece) {
-    const size_t n = fh.key_bytes - at < piece ? (size_t)(fh.key_bytes - at) : piece;
-    size_t got = 0;
-    while (got < n) {
-      ssize_t r = pread(fd, (char*)stage + got, n - got, (off_t)(fh.offset + at + got));
-      if (r < 0 && errno == EINTR) continue;
-      if (r <= 0) { rc = qh_fail(QH_EIO, "Failed to read in file '%s'", path); break; }
-      got += (size_t)r;
+  void* stage[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+    e = hipHostMalloc(&stage[i], piece, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+  }
+  if (e != hipSuccess) {
+    for (int i = 0; i < 2; ++i) { if (stage[i]) (void)hipHostFree(stage[i]); if (ev[i]) (void)hipEventDestroy(ev[i]); }
+    close(fd); qh_query_close(q);
+    return qh_fail(QH_ENOMEM, "cannot allocate the staging buffers");
+  }
+  const uint64_t image_off = fh.offset;
+  auto read_piece = [&](char* dst, size_t n, uint64_t at) -> bool {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 8) nt = 8;
+    if (nt < 1 || n < ((size_t)16 << 20)) nt = 1;
+    const size_t slice = ((n + nt - 1) / nt + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    std::vector<char> bad(nt, 0);
+    for (unsigned t = 0; t < nt; ++t) {
+      const size_t from = (size_t)t * slice, to = from + slice < n ? from + slice : n;
+      if (from >= to) break;
+      th.emplace_back([=, &bad]() {
+        size_t got = from;
+        while (got < to) {
+          ssize_t r = pread(fd, dst + got, to - got, (off_t)(image_off + at + got));
+          if (r < 0 && errno == EINTR) continue;
+          if (r <= 0) { bad[t] = 1; return; }
+          got += (size_t)r;
+        }
+      });
     }
-    if (rc) break;
-    e = hipMemcpyAsync((char*)q->table + at, stage, n, hipMemcpyHostToDevice, q->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(q->stream);
+    for (auto& x : th) x.join();
+    for (char c : bad) if (c) return false;
+    return true;
+  };
+  rc = QH_OK;
+  bool used[2] = {false, false};
+  int b = 0;
+  for (uint64_t at = 0; at < fh.key_bytes && rc == QH_OK; at += piece, b ^= 1) {
+    const size_t n = fh.key_bytes - at < piece ? (size_t)(fh.key_bytes - at) : piece;
+    if (used[b]) {  // the copy that last read this piece must be done before the file overwrites it
+      e = hipEventSynchronize(ev[b]);
+      if (e != hipSuccess) { rc = qh_fail(QH_EHIP, "copying the table to the device failed: %s", hipGetErrorString(e)); break; }
+    }
+    if (!read_piece((char*)stage[b], n, at)) { rc = qh_fail(QH_EIO, "Failed to read in file '%s'", path); break; }
+    e = hipMemcpyAsync((char*)q->table + at, stage[b], n, hipMemcpyHostToDevice, q->stream);
+    if (e == hipSuccess) e = hipEventRecord(ev[b], q->stream);
+    used[b] = true;
     if (e != hipSuccess) rc = qh_fail(QH_EHIP, "copying the table to the device failed: %s", hipGetErrorString(e));
   }
-  e = hipHostFree(stage); (void)e;
+  e = hipStreamSynchronize(q->stream);
+  if (e != hipSuccess && rc == QH_OK) rc = qh_fail(QH_EHIP, "copying the table to the device failed: %s", hipGetErrorString(e));
+  for (int i = 0; i < 2; ++i) { (void)hipHostFree(stage[i]); (void)hipEventDestroy(ev[i]); }
   close(fd);
   if (rc) { qh_query_close(q); return rc; }
   *out = q;
