@@ -23,6 +23,7 @@
 #include <unistd.h>
 #include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/quorum_hip.h"
@@ -182,15 +183,44 @@ static void write_all(int fd, const char* p, size_t n, const std::string& name) 
   }
 }
 
-static size_t read_some(int fd, char* dst, size_t n) {
-  size_t got = 0;
-  while (got < n) {
-    ssize_t r = read(fd, dst + got, n - got);
-    if (r < 0) { if (errno == EINTR) continue; die(std::string("read error: ") + strerror(errno)); }
-    if (r == 0) break;
-    got += (size_t)r;
+// Fills dst[0, n) from the file: a regular file is read by a few threads at once (pread of disjoint slices: the
+// page-cache copy is what bounds the tool), anything else sequentially.
+static size_t read_some(int fd, bool regular, off_t* pos, char* dst, size_t n) {
+  if (!regular) {
+    size_t got = 0;
+    while (got < n) {
+      ssize_t r = read(fd, dst + got, n - got);
+      if (r < 0) { if (errno == EINTR) continue; die(std::string("read error: ") + strerror(errno)); }
+      if (r == 0) break;
+      got += (size_t)r;
+    }
+    return got;
   }
-  return got;
+  struct stat st;
+  if (fstat(fd, &st) != 0) die(std::string("fstat: ") + strerror(errno));
+  const size_t left = st.st_size > *pos ? (size_t)(st.st_size - *pos) : 0;
+  if (n > left) n = left;
+  const size_t min_slice = (size_t)8 << 20;
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt > 8) nt = 8;
+  if (nt < 1 || n < 2 * min_slice) nt = 1;
+  const size_t slice = (n + nt - 1) / nt;
+  bool failed = false;
+  auto work = [&](size_t from, size_t to) {
+    while (from < to) {
+      ssize_t r = pread(fd, dst + from, to - from, *pos + (off_t)from);
+      if (r < 0) { if (errno == EINTR) continue; failed = true; return; }
+      if (r == 0) { failed = true; return; }  // file shrank under us
+      from += (size_t)r;
+    }
+  };
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, (size_t)t * slice, ((size_t)t + 1) * slice < n ? ((size_t)t + 1) * slice : n);
+  work(0, slice < n ? slice : n);
+  for (auto& t : th) t.join();
+  if (failed) die("read error");
+  *pos += (off_t)n;
+  return n;
 }
 
 int main(int argc, char* argv[]) {
@@ -265,9 +295,12 @@ int main(int argc, char* argv[]) {
     if (fd < 0) die(std::string("Can't open file '") + path + "'");
     size_t have = 0;
     bool eof = false;
+    struct stat fst;
+    const bool regular = fd != 0 && fstat(fd, &fst) == 0 && S_ISREG(fst.st_mode);
+    off_t fpos = 0;
     while (!eof || have) {
       if (!eof && have < cap) {
-        const size_t want = cap - have, r = read_some(fd, buf + have, want);
+        const size_t want = cap - have, r = read_some(fd, regular, &fpos, buf + have, want);
         have += r;
         if (r < want) eof = true;
       }
