@@ -172,6 +172,28 @@ def test_format_fallback_and_errors():
     assert h4.done()["instances"] == 1
 
 
+def test_burst_of_tiny_records_takes_the_host_parser():
+    """the GPU indexer keeps at most 4096 newlines per 16 KiB of text (lines of 4 bytes on average); a chunk whose records
+    are long enough on average but holds a burst of 12-byte records is rejected by the fast path as a whole (nothing
+    inserted) and goes through the sequential parser, like every other layout the fast path does not take"""
+    k, bits = 3, 7
+    rng = np.random.default_rng(11)
+    long_recs = random_fastq(rng, 400, k=k, genome=rng.integers(0, 4, size=5000))
+    burst = b"".join(b"@\n" + bytes([b"ACGT"[i & 3]]) * 3 + b"\n+\nIII\n" for i in range(3000))   # 12 bytes, 4 lines each
+    data = long_recs + burst + long_recs
+    assert len(data) / (data.count(b"\n") // 4) > 16                     # passes the chunk-wide record count check
+    h = qa.HashWithQuality(1 << 12, 2 * k, bits, min_qual=38)
+    h.add_fastq(data)
+    with pytest.raises(qa.QhError) as ei:
+        h.sync()
+    assert ei.value.status == _lib.QH_EFORMAT and h.stats()["instances"] == 0
+    h.add_fastq_host_parsed(data, final=True)
+    st = h.done()
+    db, n, om, ov = oracle_build(data, k, bits, 38, size=1 << 12)
+    m, v = sorted_pairs(*h.dump())
+    assert st["instances"] == n and (m == om).all() and (v == ov).all()
+
+
 def test_empty_and_degenerate_inputs():
     h = qa.HashWithQuality(64, 48, 7, min_qual=38)
     h.add_fastq(b"")
