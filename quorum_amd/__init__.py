@@ -9,5 +9,5 @@ the library has not been built.
 """
 from ._lib import lib, QhError, last_error  # noqa: F401
 from .mer_database import (HashWithQuality, DatabaseQuery, mer_from_str, mer_to_str, revcomp, canonical,  # noqa: F401
-                           poisson_term, contaminant_database, detect_min_qual_char)
+                           poisson_term, contaminant_database, detect_min_qual_char, jf_write_file, jf_read_file)
 from .error_correct import ErrorCorrector  # noqa: F401
