@@ -88,7 +88,11 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # QH_FORCE_PIPELINE=1 (under torch.distributed.run --nproc-per-node 1): the one rank takes the N>1 route, process group,
+    # RCCL all-to-all (to itself) and all -- the rehearsal of that route a one-GPU box allows
+    pipe = bool(os.environ.get("QH_FORCE_PIPELINE")) and world == 1
+    grouped = world > 1 or pipe
+    if grouped:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -126,7 +130,7 @@ def main():
         torch.cuda.empty_cache()
     torch.cuda.synchronize()
 
-    b = ShardedBuilder(K, BITS, total_size, MIN_QUAL, rank, world, local)
+    b = ShardedBuilder(K, BITS, total_size, MIN_QUAL, rank, world, local, force_pipeline=pipe)
     b.h.set_mode(args.mode, args.level1_bits)
     b.h.enable_timing(True)
 
@@ -139,7 +143,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -159,7 +163,7 @@ def main():
     rdev = dev if backend == "nccl" else torch.device("cpu")
     t = torch.tensor([dt], dtype=torch.float64, device=rdev)
     inst = torch.tensor([float(st["instances"])], dtype=torch.float64, device=rdev)
-    if world > 1:
+    if grouped:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(inst, op=dist.ReduceOp.SUM)
     dt = float(t.item())
@@ -171,10 +175,11 @@ def main():
         partitioned = ktimes[3][1] > 0
         # names as rocprofv3 prints them: k_partition<0, ...> = FASTQ source (level 1), k_partition<1, ...> = item source
         # (owner check; class of k: 0 is k >= 12)
-        knames = ("segments(k_rec_segs_sum+k_scan_u32+k_rec_segs_apply)" if partitioned and world == 1
-                  else "k_build_direct" if world == 1 else "k_insert_items",
-                  "k_partition<0, false, 0>" if world == 1 else "k_partition<1, false, 0> (level 1)",
-                  "k_partition<1, false, 0>" if world == 1 else "k_partition<1, false, 0> (level 2)",
+        single = not grouped
+        knames = ("segments(k_rec_segs_sum+k_scan_u32+k_rec_segs_apply)" if partitioned and single
+                  else "k_build_direct" if single else "k_insert_items",
+                  "k_partition<0, false, 0>" if single else "k_partition<1, false, 0> (level 1)",
+                  "k_partition<1, false, 0>" if single else "k_partition<1, false, 0> (level 2)",
                   "k_window_count<true>")  # the counting form with 16-bit counters at this geometry
         step_s = dt / args.steps
         per_gpu_step = per_step / world             # insertions per GPU and step (the roofline is a per-GPU quantity)
@@ -223,10 +228,11 @@ def main():
                                     "in HBM; step = clear + per piece (index + extract by owner%s + insert), pieces pipelined"
                                     % (genome_bases // 1_000_000, reads_rank * world, READ_LEN, reads_rank, args.piece_reads, K,
                                        total_size // 1_000_000, world, BITS, MIN_QUAL,
-                                       " + all-to-all exchange" if world > 1 else "")),
+                                       " + all-to-all exchange" if grouped else "")),
                        "insertions_per_step": int(per_step), "distinct_per_gpu": int(st["distinct"]),
                        "slots_per_gpu": int(st["slots"]), "pieces_per_gpu": len(pieces),
-                       "bucket_overflow_retries": int(getattr(b, "retries", 0)), "parallelism": "hash-sharded x%d" % world},
+                       "bucket_overflow_retries": int(getattr(b, "retries", 0)),
+                       "exchange_rounds_max": int(getattr(b, "rounds_max", 0)), "parallelism": "hash-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "scope": "whole step (every kernel of one build): algorithmic bytes / step time",
@@ -255,7 +261,7 @@ def main():
                 fq = pieces[0].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(fq, piece_reads[0])
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -50,6 +50,12 @@ struct rccl_api {
     return CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv;
   }
 };
+// largest single RCCL message in items (512 MiB); QH_EXCHANGE_MAX_ITEMS lowers or raises it (tests)
+uint64_t max_message_items() {
+  const char* e = getenv("QH_EXCHANGE_MAX_ITEMS");
+  const long long v = e ? atoll(e) : 0;
+  return v > 0 ? (uint64_t)v : (1ull << 26);
+}
 const int kNcclUint64 = 5;  // ncclUint64 (rccl.h: ncclInt8 0, ncclUint8 1, ncclInt32 2, ncclUint32 3, ncclInt64 4, ncclUint64 5)
 
 class round_barrier {
@@ -160,7 +166,10 @@ extern "C" int qh_multi_create(qh_multi** out, int k, int bits, uint64_t size, i
   }
   // transport: RCCL between distinct devices unless QH_MULTI_TRANSPORT=copy; shards that share a device can only copy
   const char* tr = getenv("QH_MULTI_TRANSPORT");
-  const bool want_rccl = n_devices > 1 && distinct && !(tr && !strcmp(tr, "copy"));
+  // (one device with QH_MULTI_TRANSPORT=rccl: the communicator, the grouped send / receive and the rounds run with
+  // the shard sending to itself -- the rehearsal a one-GPU box allows)
+  const bool force_rccl = tr && !strcmp(tr, "rccl");
+  const bool want_rccl = (n_devices > 1 || force_rccl) && distinct && !(tr && !strcmp(tr, "copy"));
   if (want_rccl && m->nccl.load()) {
     std::vector<void*> comms(n_devices, nullptr);
     std::vector<int> devs(n_devices);
@@ -313,16 +322,28 @@ extern "C" int qh_multi_add_fastq(qh_multi* m, const char* buf, size_t len, int 
         // the insert of two rounds ago read this buffer: it completed before the previous round's insert was queued
         hipError_t e = hipSuccess;
         if (m->use_rccl) {
-          int nrc = m->nccl.GroupStart();
-          uint64_t at = 0;
-          for (int t = 0; t < n && nrc == 0; ++t) {
-            const uint64_t out_n = m->counts[(size_t)d * n + t], in_n = m->counts[(size_t)t * n + d];
-            if (out_n) nrc = m->nccl.Send(s.d_buckets + (size_t)t * s.bucket_cap, out_n, kNcclUint64, t, s.comm, s.xs);
-            if (nrc == 0 && in_n) nrc = m->nccl.Recv(s.d_recv[slot] + at, in_n, kNcclUint64, t, s.comm, s.xs);
-            at += in_n;
+          // Messages are capped (kMaxMessageItems): this image's RCCL delivered only the first half of a 1.6 GB message,
+          // without an error (tools/rccl_self_check.py; up to 1 GiB arrives whole). Round r carries items
+          // [r * cap, (r + 1) * cap) of every message; all threads see the same count matrix, hence the same rounds.
+          uint64_t largest = 0;
+          for (size_t i = 0; i < (size_t)n * n; ++i) largest = std::max<uint64_t>(largest, m->counts[i]);
+          const uint64_t cap_items = max_message_items();
+          const uint64_t rounds = std::max<uint64_t>(1, (largest + cap_items - 1) / cap_items);
+          int nrc = 0;
+          for (uint64_t r = 0; r < rounds && nrc == 0; ++r) {
+            nrc = m->nccl.GroupStart();
+            uint64_t at = 0;
+            for (int t = 0; t < n && nrc == 0; ++t) {
+              const uint64_t out_n = m->counts[(size_t)d * n + t], in_n = m->counts[(size_t)t * n + d];
+              const uint64_t olo = std::min(out_n, r * cap_items), ohi = std::min(out_n, (r + 1) * cap_items);
+              const uint64_t ilo = std::min(in_n, r * cap_items), ihi = std::min(in_n, (r + 1) * cap_items);
+              if (ohi > olo) nrc = m->nccl.Send(s.d_buckets + (size_t)t * s.bucket_cap + olo, ohi - olo, kNcclUint64, t, s.comm, s.xs);
+              if (nrc == 0 && ihi > ilo) nrc = m->nccl.Recv(s.d_recv[slot] + at + ilo, ihi - ilo, kNcclUint64, t, s.comm, s.xs);
+              at += in_n;
+            }
+            const int erc = m->nccl.GroupEnd();
+            if (nrc == 0) nrc = erc;
           }
-          const int erc = m->nccl.GroupEnd();
-          if (nrc == 0) nrc = erc;
           if (nrc != 0) { qh_fail(QH_EHIP, "RCCL exchange failed: %s", m->nccl.GetErrorString ? m->nccl.GetErrorString(nrc) : "?"); fail_here(s, QH_EHIP); break; }
         } else {
           uint64_t at = 0;

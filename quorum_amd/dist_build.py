@@ -8,6 +8,7 @@ torch is plumbing here: device buffers, the collective and streams. Extraction,
 bucketing and insertion are the library's kernels (include/quorum_hip.h)."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -133,50 +134,105 @@ def owner_np(mers, k, shard_bits):
     return (hash_np(mers, k) & np.uint64((1 << shard_bits) - 1)).astype(np.int64)
 
 
+# Largest single message of an exchange, in items. Measured on this image (tools/rccl_self_check.py, RCCL 2.26.6, one
+# rank sending to itself): messages up to 1 GiB arrive whole, a 1.6 GB one arrives with its second half missing and no
+# error. Every exchange is therefore cut into rounds whose messages stay at or below 512 MiB.
+MAX_MESSAGE_ITEMS = 1 << 26
+
+
+def _max_message_items():
+    return max(1, int(os.environ.get("QH_EXCHANGE_MAX_ITEMS", MAX_MESSAGE_ITEMS)))
+
+
+def gather_counts(counts, group=None, device=None):
+    """Every rank's per-destination counts -> the world x world matrix m[src][dst] as python lists (one small
+    all-gather): each rank learns what it will receive AND how many rounds the largest message of the job needs."""
+    world = dist.get_world_size(group)
+    dev = device if device is not None else torch.device("cpu")
+    sc = torch.tensor(list(counts), dtype=torch.int64, device=dev)
+    rows = [torch.empty(world, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(rows, sc, group=group)
+    return torch.stack(rows).tolist()
+
+
+def _rounds_of(matrix, limit):
+    return max(1, -(-max(max(r) for r in matrix) // limit))
+
+
+_LIST_ALL_TO_ALL_OK = True
+
+
+def _run_exchange(send_rows, counts, recv, recv_counts, rounds, limit, group, async_op=False):
+    """send_rows[s]: 1-D tensor whose first counts[s] items go to rank s; recv: 1-D tensor that receives
+    sum(recv_counts) items, source after source. Round t carries items [t*limit, (t+1)*limit) of every message.
+    With RCCL the parts are sent and received where they lie (list form); otherwise each round is packed.
+    Returns the list of pending work handles (empty unless async_op and the list form was taken)."""
+    global _LIST_ALL_TO_ALL_OK
+    world = len(counts)
+    offs = [0]
+    for c in recv_counts:
+        offs.append(offs[-1] + c)
+    nccl = recv.device.type == "cuda" and dist.get_backend(group) == "nccl"
+    works = []
+    for t in range(rounds):
+        lo = [min(c, t * limit) for c in counts]
+        hi = [min(c, (t + 1) * limit) for c in counts]
+        rlo = [min(c, t * limit) for c in recv_counts]
+        rhi = [min(c, (t + 1) * limit) for c in recv_counts]
+        ins = [send_rows[s][lo[s]:hi[s]] for s in range(world)]
+        outs = [recv[offs[s] + rlo[s]:offs[s] + rhi[s]] for s in range(world)]
+        if nccl and _LIST_ALL_TO_ALL_OK:
+            try:
+                w = dist.all_to_all(outs, ins, group=group, async_op=async_op)
+                if async_op:
+                    works.append(w)
+                continue
+            except (RuntimeError, NotImplementedError):
+                _LIST_ALL_TO_ALL_OK = False   # every rank fails alike (same torch build): fall back together
+        packed = torch.cat(ins)
+        got = torch.empty(sum(rhi[s] - rlo[s] for s in range(world)), dtype=recv.dtype, device=recv.device)
+        dist.all_to_all_single(got, packed, output_split_sizes=[rhi[s] - rlo[s] for s in range(world)],
+                               input_split_sizes=[hi[s] - lo[s] for s in range(world)], group=group)
+        for o, g in zip(outs, got.split([rhi[s] - rlo[s] for s in range(world)])):
+            o.copy_(g)
+    return works
+
+
 def exchange_items(send, send_counts, group=None):
     """One all-to-all(v) of packed items (mer<<1|hq as int64).
 
     send: 1-D int64 tensor, the items for rank 0, then rank 1, ... back to back;
     send_counts: python list of per-destination counts. Returns (recv, recv_counts).
     Works on CUDA tensors (RCCL) and CPU tensors (gloo)."""
-    world = dist.get_world_size(group)
     dev = send.device
     if dev.type == "cuda" and dist.get_backend(group) == "gloo":
         # rehearsal mode (several ranks sharing one GPU, no RCCL): stage through the host
         recv, recv_counts = exchange_items(send.cpu(), send_counts, group)
         return recv.to(dev), recv_counts
-    sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
-    rc = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_to_all_single(rc, sc, group=group)
-    recv_counts = rc.tolist()
+    rank = dist.get_rank(group)
+    m = gather_counts(send_counts, group, dev)
+    recv_counts = [row[rank] for row in m]
     recv = torch.empty(int(sum(recv_counts)), dtype=torch.int64, device=dev)
-    dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=list(send_counts), group=group)
+    limit = _max_message_items()
+    _run_exchange(list(send.split(list(send_counts))), list(send_counts), recv, recv_counts, _rounds_of(m, limit), limit, group)
     return recv, recv_counts
 
 
-_LIST_ALL_TO_ALL_OK = True
-
-
 def exchange_buckets(buckets, counts, group=None):
-    """The same exchange straight from the per-destination bucket rows (2-D int64 CUDA tensor,
-    counts[s] items of row s are for rank s): with RCCL the rows are sent where they lie
-    (dist.all_to_all over views), which saves packing 8 bytes per item into one send buffer; any
-    other backend, or a torch build that refuses the list form, takes exchange_items."""
-    global _LIST_ALL_TO_ALL_OK
-    world = dist.get_world_size(group)
-    if _LIST_ALL_TO_ALL_OK and buckets.device.type == "cuda" and dist.get_backend(group) == "nccl":
-        try:
-            sc = torch.tensor(counts, dtype=torch.int64, device=buckets.device)
-            rc = torch.empty(world, dtype=torch.int64, device=buckets.device)
-            dist.all_to_all_single(rc, sc, group=group)
-            recv_counts = rc.tolist()
-            recv = torch.empty(int(sum(recv_counts)), dtype=torch.int64, device=buckets.device)
-            dist.all_to_all(list(recv.split(recv_counts)), [buckets[s, :counts[s]] for s in range(world)], group=group)
-            return recv, recv_counts
-        except (RuntimeError, NotImplementedError):
-            _LIST_ALL_TO_ALL_OK = False  # every rank fails alike (same torch build): fall back together
-    send = torch.cat([buckets[s, :counts[s]] for s in range(world)])
-    return exchange_items(send, counts, group)
+    """The same exchange straight from the per-destination bucket rows (2-D int64 tensor, counts[s] items of row s
+    are for rank s): with RCCL the rows are sent where they lie, which saves packing 8 bytes per item into one send
+    buffer."""
+    dev = buckets.device
+    if dev.type == "cuda" and dist.get_backend(group) == "gloo":
+        recv, recv_counts = exchange_buckets(buckets.cpu(), counts, group)
+        return recv.to(dev), recv_counts
+    rank = dist.get_rank(group)
+    m = gather_counts(counts, group, dev)
+    recv_counts = [row[rank] for row in m]
+    recv = torch.empty(int(sum(recv_counts)), dtype=torch.int64, device=dev)
+    limit = _max_message_items()
+    _run_exchange([buckets[s] for s in range(len(counts))], list(counts), recv, recv_counts, _rounds_of(m, limit), limit, group)
+    return recv, recv_counts
 
 
 class ShardedBuilder:
@@ -193,7 +249,7 @@ class ShardedBuilder:
     flush() drain the pipeline."""
 
     def __init__(self, k, bits, total_size, min_qual, rank, world, device, reprobe_limit=126, group=None,
-                 cap_factor=1.25):
+                 cap_factor=1.25, force_pipeline=False):
         from .mer_database import HashWithQuality
         self.cap_factor = cap_factor     # bucket capacity = mean share x this (tests lower it to force the retry)
         assert world & (world - 1) == 0, "number of shards must be a power of two"
@@ -204,7 +260,10 @@ class ShardedBuilder:
                                  reprobe_limit=reprobe_limit, shard_bits=self.shard_bits, shard_id=rank)
         self.hx = None           # extraction handle (its table is never used: smallest size)
         self._ins_stream = None
-        if world > 1:
+        # force_pipeline: a single rank takes the extract / exchange / insert route too (the collective then sends to
+        # itself): the way to run the RCCL calls of this file on a one-GPU machine
+        self.pipelined = world > 1 or force_pipeline
+        if self.pipelined:
             self.hx = HashWithQuality(1 << 13, 2 * k, bits, min_qual=min_qual, device=device,
                                       reprobe_limit=reprobe_limit, shard_bits=self.shard_bits, shard_id=rank)
             self._ins_stream = torch.cuda.Stream(self.device)
@@ -218,6 +277,7 @@ class ShardedBuilder:
         self._inflight = None            # (piece index, work handle or None, recv tensor, recv count)
         self._npieces = 0
         self.retries = 0                 # bucket overflows that were resolved by a larger capacity
+        self.rounds_max = 0              # most rounds any exchange needed (messages are capped, see MAX_MESSAGE_ITEMS)
 
     # ---- stage 1
     def _extract(self, chunk, max_items, slot):
@@ -246,14 +306,15 @@ class ShardedBuilder:
 
     # ---- stage 2
     def _start_exchange(self, slot, counts):
-        """counts ahead, then the items; returns (work or None, recv tensor, number received)"""
+        """counts ahead (every rank learns the whole matrix), then the items in as many rounds as the job's largest
+        message needs; returns (list of work handles, recv tensor, number received)"""
         world, dev = self.world, self.device
         staged = dist.get_backend(self.group) != "nccl"     # rehearsal (several ranks on one GPU over gloo): through the host
-        cdev = torch.device("cpu") if staged else dev
-        sc = torch.tensor(counts, dtype=torch.int64, device=cdev)
-        rc = torch.empty(world, dtype=torch.int64, device=cdev)
-        dist.all_to_all_single(rc, sc, group=self.group)
-        recv_counts = rc.tolist()
+        m = gather_counts(counts, self.group, torch.device("cpu") if staged else dev)
+        recv_counts = [row[self.rank] for row in m]
+        limit = _max_message_items()
+        rounds = _rounds_of(m, limit)
+        self.rounds_max = max(self.rounds_max, rounds)
         n = int(sum(recv_counts))
         r = self._recv[slot]
         if r is None or r.numel() < n:
@@ -261,32 +322,25 @@ class ShardedBuilder:
         b = self._buckets[slot]
         if b is None:                  # this rank had nothing to extract yet
             b = self._buckets[slot] = torch.empty((world, 1), dtype=torch.int64, device=dev)
-        send = [b[s, :counts[s]] for s in range(world)]
-        if staged:   # gloo has no list form: one packed buffer
+        if staged:   # gloo: host tensors
             got = torch.empty(n, dtype=torch.int64)
-            dist.all_to_all_single(got, torch.cat([x.cpu() for x in send]), output_split_sizes=recv_counts,
-                                   input_split_sizes=list(counts), group=self.group)
+            _run_exchange([b[s, :counts[s]].cpu() for s in range(world)], counts, got, recv_counts, rounds, limit, self.group)
             r[:n].copy_(got)
             torch.cuda.current_stream(dev).synchronize()
-            return None, r, n
-        global _LIST_ALL_TO_ALL_OK
-        if _LIST_ALL_TO_ALL_OK:
-            try:   # the bucket rows are sent where they lie
-                work = dist.all_to_all(list(r[:n].split(recv_counts)), send, group=self.group, async_op=True)
-                return work, r, n
-            except (RuntimeError, NotImplementedError):
-                _LIST_ALL_TO_ALL_OK = False   # every rank fails alike (same torch build): fall back together
-        packed = torch.cat(send)
-        work = dist.all_to_all_single(r[:n], packed, output_split_sizes=recv_counts, input_split_sizes=list(counts),
-                                      group=self.group, async_op=True)
-        self._packed = packed                 # alive until the exchange has completed
-        return work, r, n
+            return [], r, n
+        works = _run_exchange([b[s] for s in range(world)], counts, r[:n], recv_counts, rounds, limit, self.group, async_op=True)
+        # the packed fallback works on the current stream: the shard handle's stream must follow that too
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self._ins_stream.wait_event(ev)
+        return works, r, n
 
     # ---- stage 3
-    def _insert(self, slot, work, recv, n):
-        if work is not None:
+    def _insert(self, slot, works, recv, n):
+        if works is not None:
             with torch.cuda.stream(self._ins_stream):
-                work.wait()                       # the shard handle's stream waits for the items; the host does not
+                for w in works:
+                    w.wait()                      # the shard handle's stream waits for the items; the host does not
                 ev = torch.cuda.Event()
                 ev.record(self._ins_stream)
             self._sent_done[slot] = ev
@@ -298,7 +352,7 @@ class ShardedBuilder:
     def add_fastq_device(self, chunk, max_items=None):
         """chunk: 1-D uint8 CUDA tensor holding strict 4-line FASTQ records (None: this rank has no more reads but
         other ranks may). The chunk must stay alive until the next call returns."""
-        if self.world == 1:
+        if not self.pipelined:
             if chunk is not None and chunk.numel():
                 self.h.add_fastq_device(chunk.data_ptr(), chunk.numel())
             return

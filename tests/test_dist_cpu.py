@@ -40,7 +40,9 @@ def _rank_items(rank, world, k):
     return np.concatenate(mers), np.concatenate(hqs)
 
 
-def _worker(rank, world, port, k, bits, outdir):
+def _worker(rank, world, port, k, bits, outdir, max_items=0):
+    if max_items:
+        os.environ["QH_EXCHANGE_MAX_ITEMS"] = str(max_items)   # messages cut into rounds of this many items
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from quorum_amd.dist_build import exchange_items, owner_np
@@ -57,6 +59,13 @@ def _worker(rank, world, port, k, bits, outdir):
         recv, recv_counts = exchange_items(send, counts)
         got = recv.numpy().view(np.uint64)
         assert got.size == sum(recv_counts)
+        if max_items:   # the same through the bucket-row form, which must deliver the same items in the same order
+            from quorum_amd.dist_build import exchange_buckets
+            rows = torch.zeros((world, max(counts) + 3), dtype=torch.int64)
+            for s_, part in enumerate(send.split(counts)):
+                rows[s_, :counts[s_]] = part
+            recv2, rc2 = exchange_buckets(rows, counts)
+            assert rc2 == recv_counts and torch.equal(recv2, recv)
         gm, gq = got >> np.uint64(1), (got & np.uint64(1)).astype(np.uint8)
         assert (owner_np(gm, k, shard_bits) == rank).all()      # only what this shard owns arrives
         db = po.OracleDB(1 << 16, k, bits)
@@ -67,11 +76,13 @@ def _worker(rank, world, port, k, bits, outdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_exchange_gloo(world, tmp_path):
+@pytest.mark.parametrize("world,max_items", [(2, 0), (4, 0), (2, 7001), (4, 1000)])
+def test_sharded_exchange_gloo(world, max_items, tmp_path):
+    """max_items: the cap on a single message (dist_build.MAX_MESSAGE_ITEMS), lowered so that the ~15-30 k items a pair
+    exchanges here travel in several rounds, the last one ragged"""
     k, bits = 21, 7
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, k, bits, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, k, bits, str(tmp_path), max_items), nprocs=world, join=True)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
     ref = po.OracleDB(1 << 16, k, bits)

@@ -176,3 +176,125 @@ def test_pipelined_sharded_builder_two_ranks(tmp_path):
     sm, sv = sorted_pairs(m, v)
     assert (sm == mm.numpy().view(np.uint64)).all() and (sv == mv.numpy().view(np.uint64)).all()
     assert (owner_np(r[0]["m"], 24, 1) == 0).all() and (owner_np(r[1]["m"], 24, 1) == 1).all()
+
+
+def _rccl_self_rank(rank, world, port, outdir):
+    """the one rank of test_pipeline_over_rccl_single_rank"""
+    import os
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch_model as tm
+    os.environ["QH_EXCHANGE_MAX_ITEMS"] = "600000"     # a piece of ~2.5 M items travels in several capped rounds
+    from quorum_amd.dist_build import ShardedBuilder, exchange_buckets, exchange_items
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    try:
+        k, bits, thresh, L = 24, 7, 38, 100
+        genome = tm.make_genome(300_000, "cuda:0")
+        b = ShardedBuilder(k, bits, 1 << 23, thresh, 0, 1, 0, cap_factor=0.4, force_pipeline=True)
+        canon, hq = [], []
+        for i in range(4):
+            if i == 2:
+                b.add_fastq_device(None)       # a piece with nothing in it travels too
+                continue
+            codes, qual, isN = tm.make_reads(genome, 30_000 + 5_000 * i, L, seed=i, tails=True)
+            chunk = tm.fastq_text(codes, qual, isN)
+            c, q = tm.model_items(codes, qual, isN, k, thresh)
+            canon.append(c.cpu())
+            hq.append(q.cpu())
+            torch.cuda.synchronize()
+            b.add_fastq_device(chunk)
+        st = b.finish()
+        m, v = b.h.dump()
+        # the two stand-alone exchange helpers over RCCL as well
+        rows = torch.arange(40, dtype=torch.int64, device=dev).reshape(1, 40)
+        got, rc = exchange_buckets(rows, [17])
+        got2, rc2 = exchange_items(rows[0, :9].contiguous(), [9])
+        torch.cuda.synchronize()
+        np.savez(os.path.join(outdir, "rccl.npz"), m=m, v=v, canon=torch.cat(canon).numpy(), hq=torch.cat(hq).numpy(),
+                 inst=np.array([st["instances"]]), retries=np.array([b.retries, b.rounds_max]), got=got.cpu().numpy(),
+                 got2=got2.cpu().numpy(), rc=np.array(rc + rc2))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipeline_over_rccl_single_rank(tmp_path):
+    """The RCCL calls of the sharded build on the hardware there is: one rank, backend "nccl", the pipeline forced
+    (extract by owner -> counts ahead -> list-form all-to-all started asynchronously -> insert on the shard handle's stream
+    after work.wait()), the message cap lowered so that every piece takes several rounds. The collective sends to itself,
+    but it is the same torch.distributed / RCCL call sequence the N > 1 bench issues; content against the independent
+    model."""
+    import socket
+    import torch.multiprocessing as mp
+    import torch_model as tm
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    mp.start_processes(_rccl_self_rank, args=(1, port, str(tmp_path)), nprocs=1, join=True, start_method="spawn")
+    r = np.load(str(tmp_path / "rccl.npz"))
+    mm, mv = tm.model_table(torch.from_numpy(r["canon"]), torch.from_numpy(r["hq"]), 7)
+    assert int(r["inst"][0]) == r["canon"].size and int(r["retries"][0]) >= 1 and int(r["retries"][1]) >= 3
+    sm, sv = sorted_pairs(r["m"], r["v"])
+    assert (sm == mm.numpy().view(np.uint64)).all() and (sv == mv.numpy().view(np.uint64)).all()
+    assert (r["got"] == np.arange(17)).all() and (r["got2"] == np.arange(9)).all() and list(r["rc"]) == [17, 9]
+
+
+def _multi_rccl_child(outdir):
+    """qh_multi with ONE shard and the RCCL transport forced (own process: the transport is chosen from the environment)"""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["QH_MULTI_TRANSPORT"] = "rccl"
+    os.environ["QH_EXCHANGE_MAX_ITEMS"] = "300000"
+    import torch  # noqa: F401  (brings librccl.so into the process the way the tools find it)
+    from quorum_amd import _lib, synth as sy
+    k, bits = 24, 7
+    g = sy.make_genome(150000)
+    fq = sy.make_fastq(g, 40000, 100, tails=True).tobytes()
+    h = C.c_void_p()
+    _lib.check(_lib.lib.qh_multi_create(C.byref(h), k, bits, 1 << 22, 38, 126, 1, None))
+    used = C.c_size_t()
+    half = fq.index(b"\n@", len(fq) // 2) + 1
+    _lib.check(_lib.lib.qh_multi_add_fastq(h, fq[:half], half, 0, C.byref(used)))
+    assert used.value == half
+    _lib.check(_lib.lib.qh_multi_add_fastq(h, fq[half:], len(fq) - half, 1, C.byref(used)))
+    st = _lib.QhBuildStats()
+    _lib.check(_lib.lib.qh_multi_finish(h, C.byref(st)))
+    nd, rccl, rounds = C.c_int(), C.c_int(), C.c_uint64()
+    _lib.check(_lib.lib.qh_multi_info(h, C.byref(nd), C.byref(rccl), C.byref(rounds), None, None))
+    cap = int(st.distinct) + 16
+    m = np.empty(cap, dtype=np.uint64)
+    v = np.empty(cap, dtype=np.uint64)
+    n = C.c_uint64()
+    u64p = C.POINTER(C.c_uint64)
+    _lib.check(_lib.lib.qh_multi_dump(h, m.ctypes.data_as(u64p), v.ctypes.data_as(u64p), cap, C.byref(n)))
+    _lib.lib.qh_multi_destroy(h)
+    np.savez(os.path.join(outdir, "multi.npz"), m=m[:n.value], v=v[:n.value], fq=np.frombuffer(fq, dtype=np.uint8),
+             info=np.array([nd.value, rccl.value, rounds.value, st.instances]))
+
+
+def test_multi_host_over_rccl_single_shard(tmp_path):
+    """The C++ multi-GPU host's RCCL leg on the hardware there is: librccl through dlopen, ncclCommInitAll, the grouped
+    ncclSend / ncclRecv of every chunk in capped rounds (cap lowered: a chunk of ~1.5 M items takes five), here with one
+    shard sending to itself; content against the oracle."""
+    import torch.multiprocessing as mp
+    mp.start_processes(_multi_rccl_child_entry, args=(str(tmp_path),), nprocs=1, join=True, start_method="spawn")
+    r = np.load(str(tmp_path / "multi.npz"))
+    assert list(r["info"][:2]) == [1, 1] and int(r["info"][2]) == 2
+    fq = r["fq"].tobytes()
+    db = po.OracleDB(1 << 22, 24, 7)
+    n = db.add_fastq(fq, 38, threads=8)
+    assert n == int(r["info"][3])
+    om, ov = db.sorted_dump()
+    m, v = sorted_pairs(r["m"], r["v"])
+    assert m.size == om.size and (m == om).all() and (v == ov).all()
+
+
+def _multi_rccl_child_entry(rank, outdir):
+    _multi_rccl_child(outdir)
