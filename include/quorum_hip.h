@@ -398,8 +398,9 @@ int qh_corrector_correct_device(qh_corrector* c, const void* dev_buf, size_t len
 /* Waits for the chunk and hands out its two text streams: `fa` is what upstream writes to
  * <prefix>.fa (">header fwd_log bwd_log\nSEQUENCE\n", :334-336; ">header\nN\n" for a discarded
  * read under -d, :274-275), `log` what it writes to <prefix>.log ("Skipped header: reason\n",
- * :272). The pointers are library-owned pinned host memory, valid until the next call on this
- * corrector. stats may be NULL. */
+ * :272). The pointers are library-owned pinned host memory; fetches alternate between two buffers,
+ * so they stay valid through the NEXT correct + fetch on this corrector and die with the one after
+ * (a tool writes chunk i out while chunk i+1 is corrected). stats may be NULL. */
 int qh_corrector_fetch(qh_corrector* c, const char** fa, size_t* fa_len, const char** log, size_t* log_len,
                        qh_correct_stats* stats);
 

@@ -1088,8 +1088,11 @@ struct qh_corrector {
   unsigned long long* d_bsums = nullptr; size_t bsums_cap = 0;
   uint8_t* d_fa = nullptr;     size_t fa_cap = 0;
   uint8_t* d_log = nullptr;    size_t log_cap = 0;
-  char* h_fa = nullptr;        size_t h_fa_cap = 0;    // pinned
-  char* h_log = nullptr;       size_t h_log_cap = 0;   // pinned
+  // pinned, two of each: fetches alternate between them, so what one fetch returned stays valid through the next
+  // correct + fetch (a caller may write chunk i out while chunk i+1 is corrected)
+  char* h_fa[2] = {nullptr, nullptr};   size_t h_fa_cap[2] = {0, 0};
+  char* h_log[2] = {nullptr, nullptr};  size_t h_log_cap[2] = {0, 0};
+  int h_out = 0;
   qh_meta* d_meta = nullptr;   qh_meta* h_meta = nullptr;
   qh_ec_totals* d_tot = nullptr; qh_ec_totals* h_tot = nullptr;
   hipEvent_t ev[4] = {};
@@ -1119,7 +1122,7 @@ extern "C" void qh_corrector_destroy(qh_corrector* c) {
   void* dptrs[] = {c->own_table, c->d_P, c->d_ptab, c->d_chunk, c->d_recs, c->d_hdr, c->d_tiles, c->d_nlplane, c->d_obuf, c->d_logs,
                    c->d_res, c->d_bsums, c->d_fa, c->d_log, c->d_meta, c->d_tot};
   for (void* p : dptrs) if (p) (void)hipFree(p);
-  void* hptrs[] = {c->h_fa, c->h_log, c->h_meta, c->h_tot};
+  void* hptrs[] = {c->h_fa[0], c->h_fa[1], c->h_log[0], c->h_log[1], c->h_meta, c->h_tot};
   for (void* p : hptrs) if (p) (void)hipHostFree(p);
   for (hipEvent_t e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1363,15 +1366,17 @@ extern "C" int qh_corrector_fetch(qh_corrector* c, const char** fa, size_t* fa_l
   }
   const size_t nfa = (size_t)c->h_tot->fa_bytes, nlog = (size_t)c->h_tot->log_bytes;
   int rc;
-  if ((rc = ensure_pinned(&c->h_fa, &c->h_fa_cap, nfa + 1))) return rc;
-  if ((rc = ensure_pinned(&c->h_log, &c->h_log_cap, nlog + 1))) return rc;
-  if (nfa) QH_HIP(hipMemcpyAsync(c->h_fa, c->d_fa, nfa, hipMemcpyDeviceToHost, c->stream));
-  if (nlog) QH_HIP(hipMemcpyAsync(c->h_log, c->d_log, nlog, hipMemcpyDeviceToHost, c->stream));
+  const int o = c->h_out;
+  c->h_out ^= 1;
+  if ((rc = ensure_pinned(&c->h_fa[o], &c->h_fa_cap[o], nfa + 1))) return rc;
+  if ((rc = ensure_pinned(&c->h_log[o], &c->h_log_cap[o], nlog + 1))) return rc;
+  if (nfa) QH_HIP(hipMemcpyAsync(c->h_fa[o], c->d_fa, nfa, hipMemcpyDeviceToHost, c->stream));
+  if (nlog) QH_HIP(hipMemcpyAsync(c->h_log[o], c->d_log, nlog, hipMemcpyDeviceToHost, c->stream));
   QH_HIP(hipStreamSynchronize(c->stream));
-  c->h_fa[nfa] = 0; c->h_log[nlog] = 0;
-  if (fa) *fa = c->h_fa;
+  c->h_fa[o][nfa] = 0; c->h_log[o][nlog] = 0;
+  if (fa) *fa = c->h_fa[o];
   if (fa_len) *fa_len = nfa;
-  if (log) *log = c->h_log;
+  if (log) *log = c->h_log[o];
   if (log_len) *log_len = nlog;
   if (stats) {
     stats->reads = c->h_tot->reads; stats->corrected = c->h_tot->corrected; stats->skipped = c->h_tot->skipped;
