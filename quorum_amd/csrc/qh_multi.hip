@@ -209,12 +209,50 @@ extern "C" int qh_multi_info(const qh_multi* m, int* n_devices, int* uses_rccl, 
   return QH_OK;
 }
 
+// The first record start at or after `from` in a chunk of strict 4-line records, found from the next few lines alone:
+// a line that starts with '@' and whose second successor starts with '+' is a header and nothing else (see
+// qh_fastq_4line_prefix). Returns false when eight lines do not settle it.
+static bool record_start_after(const char* buf, size_t len, size_t from, size_t* out) {
+  enum { LOOK = 8 };
+  size_t st[LOOK + 1];
+  int n = 0;
+  size_t p = from;
+  if (p > 0) {  // into the line that is under way: its successor is the first line seen whole
+    const char* q = p < len ? (const char*)memchr(buf + p - 1, '\n', len - (p - 1)) : nullptr;
+    if (!q) { *out = len; return true; }
+    p = (size_t)(q - buf) + 1;
+  }
+  bool reached_end = false;
+  while (n <= LOOK) {
+    if (p >= len) { reached_end = true; break; }
+    st[n++] = p;
+    const char* q = (const char*)memchr(buf + p, '\n', len - p);
+    if (!q) { reached_end = true; break; }
+    p = (size_t)(q - buf) + 1;
+  }
+  for (int i = 0; i + 2 < n; ++i)
+    if (buf[st[i]] == '@' && buf[st[i + 2]] == '+') { *out = st[i]; return true; }
+  if (reached_end) { *out = len; return true; }  // the tail of the chunk's last record: it stays with the previous part
+  return false;
+}
+
 // the n-1 cut points of a chunk of whole 4-line records: part d = [cut[d], cut[d+1]) begins at a record start
 static void split_records(const char* buf, size_t len, int n, std::vector<size_t>& cut) {
   cut.assign(n + 1, 0);
   cut[n] = len;
   if (n == 1) return;
-  // newlines per slice, counted in parallel; the record phase of a slice's first line follows from the prefix
+  {
+    bool ok = true;
+    for (int d = 1; d < n && ok; ++d) ok = record_start_after(buf, len, len * d / n, &cut[d]);
+    if (ok) {
+      for (int d = 1; d <= n; ++d) if (cut[d] < cut[d - 1]) cut[d] = cut[d - 1];
+      return;
+    }
+    cut.assign(n + 1, 0);
+    cut[n] = len;
+  }
+  // (lines too long for the look-ahead) newlines per slice, counted in parallel; the record phase of a slice's first
+  // line follows from the prefix
   std::vector<size_t> nl(n, 0);
   auto count = [&](int d) {
     const size_t a = len * d / n, b = len * (d + 1) / n;

@@ -259,3 +259,30 @@ def test_quorum_driver(tmp_path):
     (tmp_path / "odd.fastq").write_bytes(b"@r\nACGT\n+\nKKKK\n")   # minimum quality 'K' = 75: not a known offset
     r = subprocess.run(drv + ["-s", "1M", str(tmp_path / "odd.fastq")], capture_output=True, text=True)
     assert r.returncode == 1 and "unusual minimum quality char" in r.stderr
+
+
+def test_sharded_cli_strict_input_never_takes_the_host_parser(tmp_path):
+    """the parts a chunk is cut into for the shards begin at record starts (found from a few lines after each cut point):
+    with strict 4-line input, quality lines starting with '@' and '+' included, no part is rejected by the GPU indexer"""
+    k, bits = 24, 7
+    g = synth.make_genome(60000)
+    arr = synth.make_fastq(g, 20000, 100, tails=True).reshape(20000, synth.record_bytes(100))
+    arr[::7, 15 + 100] = ord("@")   # the first quality character of every seventh record
+    fq = arr.tobytes()
+    quals = fq.split(b"\n")[3::4]
+    assert sum(q.startswith(b"@") for q in quals) > 2000 and any(q.startswith(b"+") for q in quals)
+    (tmp_path / "a.fastq").write_bytes(fq)
+    out = str(tmp_path / "db.jf")
+    env = dict(os.environ, QUORUM_HIP_CHUNK_MB="1", QUORUM_HIP_VERBOSE="1")
+    r = subprocess.run([os.path.join(BIN, "quorum_create_database"), "-s", "400k", "-m", str(k), "-b", str(bits),
+                        "-q", "38", "--devices", "0,0,0,0", "-o", out, str(tmp_path / "a.fastq")],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "host-parsed chunks 0 " in r.stderr + " ", r.stderr
+    db = po.OracleDB(1 << 22, k, bits)
+    db.add_fastq(fq, 38, threads=8)
+    om, ov = db.sorted_dump()
+    q = qa.DatabaseQuery(out)
+    m, v = sorted_pairs(*q.dump())
+    assert m.size == om.size and (m == om).all() and (v == ov).all()
+    q.close()
