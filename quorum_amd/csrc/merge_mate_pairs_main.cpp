@@ -7,51 +7,94 @@
 // FASTQ, multi-line sequences and qualities concatenated) and written alternately as 4-line FASTQ,
 // a FASTA record getting '*' qualities (print_seq, :50-59). "Input files are not paired reads." when
 // one stream ends before the other. Host-only: no GPU work on this path.
+#include <errno.h>
+#include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <fstream>
-#include <iostream>
+#include <unistd.h>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 struct record { std::string header, seq, qual; };
 
-// one stream = several files read one after the other
+// one stream = several files read one after the other, in blocks of 4 MiB cut into lines with memchr (the first
+// version went through std::ifstream / std::getline: 0.43 GB/s, a fifth of what the corrector behind the pipe takes)
 class stream {
   std::vector<const char*> files_;
   size_t next_ = 0;
-  std::ifstream is_;
+  int fd_ = -1;
+  std::vector<char> buf_;
+  size_t pos_ = 0, end_ = 0;
+  bool file_eof_ = true;
+
+  bool fill() {  // more bytes of the current file behind [pos_, end_); false at its end
+    if (file_eof_) return false;
+    if (pos_ > 0) { memmove(buf_.data(), buf_.data() + pos_, end_ - pos_); end_ -= pos_; pos_ = 0; }
+    if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);  // a line longer than the buffer
+    for (;;) {
+      const ssize_t r = read(fd_, buf_.data() + end_, buf_.size() - end_);
+      if (r < 0) { if (errno == EINTR) continue; throw std::runtime_error("read error"); }
+      if (r == 0) { file_eof_ = true; return false; }
+      end_ += (size_t)r;
+      return true;
+    }
+  }
+  int peek() {  // the next character of the current file, EOF at its end
+    if (pos_ == end_ && !fill()) return EOF;
+    return (unsigned char)buf_[pos_];
+  }
+  // std::getline: the next line without its newline appended to `to` (the last line of a file may lack the newline);
+  // false when the file has ended
+  bool getline(std::string& to) {
+    if (pos_ == end_ && !fill()) return false;
+    for (;;) {
+      const char* nl = (const char*)memchr(buf_.data() + pos_, '\n', end_ - pos_);
+      if (nl) {
+        to.append(buf_.data() + pos_, (size_t)(nl - (buf_.data() + pos_)));
+        pos_ = (size_t)(nl - buf_.data()) + 1;
+        return true;
+      }
+      if (!fill()) {  // the file ends inside the line
+        to.append(buf_.data() + pos_, end_ - pos_);
+        pos_ = end_;
+        return true;
+      }
+    }
+  }
   bool open_next() {
     while (next_ < files_.size()) {
-      is_.close(); is_.clear();
-      is_.open(files_[next_++]);
-      if (!is_.good()) throw std::runtime_error(std::string("Can't open file '") + files_[next_ - 1] + "'");
-      if (is_.peek() != EOF) return true;
+      if (fd_ >= 0) close(fd_);
+      fd_ = open(files_[next_++], O_RDONLY);
+      if (fd_ < 0) throw std::runtime_error(std::string("Can't open file '") + files_[next_ - 1] + "'");
+      pos_ = end_ = 0;
+      file_eof_ = false;
+      if (peek() != EOF) return true;
     }
     return false;
   }
 public:
-  explicit stream(const std::vector<const char*>& f) : files_(f) { }
+  explicit stream(const std::vector<const char*>& f) : files_(f), buf_((size_t)4 << 20) { }
+  ~stream() { if (fd_ >= 0) close(fd_); }
   bool next(record& r) {
-    if (!is_.is_open() || is_.peek() == EOF) { if (!open_next()) return false; }
-    const int c = is_.peek();
+    if (fd_ < 0 || peek() == EOF) { if (!open_next()) return false; }
+    const int c = peek();
     r.header.clear(); r.seq.clear(); r.qual.clear();
     std::string line;
     if (c == '>') {  // read_fasta: sequence lines up to the next '>'
-      is_.get();
-      std::getline(is_, r.header);
-      while (is_.peek() != EOF && is_.peek() != '>') { std::getline(is_, line); r.seq += line; }
+      ++pos_;
+      getline(r.header);
+      while (peek() != EOF && peek() != '>') getline(r.seq);
     } else if (c == '@') {  // read_fastq
-      is_.get();
-      std::getline(is_, r.header);
-      while (is_.peek() != EOF && is_.peek() != '+') { std::getline(is_, line); r.seq += line; }
-      if (!is_.good()) throw std::runtime_error("Truncated fastq file");
-      std::getline(is_, line);  // the '+' line
-      while (r.qual.size() < r.seq.size() && is_.good()) { std::getline(is_, line); r.qual += line; }
+      ++pos_;
+      getline(r.header);
+      while (peek() != EOF && peek() != '+') getline(r.seq);
+      if (peek() == EOF) throw std::runtime_error("Truncated fastq file");
+      getline(line);  // the '+' line
+      while (r.qual.size() < r.seq.size() && getline(r.qual)) { }
       if (r.qual.size() != r.seq.size()) throw std::runtime_error("Invalid fastq file: wrong number of quals");
-      if (is_.peek() != EOF && is_.peek() != '@') throw std::runtime_error("Invalid fastq file: header missing");
+      if (peek() != EOF && peek() != '@') throw std::runtime_error("Invalid fastq file: header missing");
     } else {
       throw std::runtime_error("Unsupported format");
     }
@@ -82,6 +125,8 @@ int main(int argc, char* argv[]) {
   if (files.size() % 2 != 0) { fprintf(stderr, "Error: Must give a even number files\n"); return 1; }
   std::vector<const char*> even, odd;
   for (size_t i = 0; i < files.size(); ++i) (i % 2 ? odd : even).push_back(files[i]);
+  static char obuf[4 << 20];
+  setvbuf(stdout, obuf, _IOFBF, sizeof obuf);
   try {
     stream es(even), os(odd);
     record e, o;

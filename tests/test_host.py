@@ -183,3 +183,37 @@ def test_mate_pair_helpers(tmp_path):
     assert r.returncode == 0, r.stderr
     assert (tmp_path / "out_1.fa").read_bytes() == b">a1 x 3:sub:A-C \nACCTAC\n>a2  \nGG\n"
     assert (tmp_path / "out_2.fa").read_bytes() == b">b1\nN\n>b2 y  \nCC\n"
+
+
+def test_mate_pair_helpers_edges(tmp_path):
+    """the block readers of both helpers at their edges: last lines without a newline, a lone header at the end of the
+    corrector's stream, lines longer than a first guess, a file that ends inside a record, the quality-count error"""
+    import subprocess
+    bindir = os.path.join(ROOT, "quorum_amd", "bin")
+    split = os.path.join(bindir, "split_mate_pairs")
+    merge = os.path.join(bindir, "merge_mate_pairs")
+    for fa, one, two in ((b">a\nAC\n>b\nGT", b">a\nAC\n", b">b\nGT\n"),
+                         (b">a\nAC\n>b\n", b">a\nAC\n", b">b\n\n"),
+                         (b">a\nAC\n>b", b">a\nAC\n", b">b\n\n"),
+                         (b"", b"", b"")):
+        r = subprocess.run([split, str(tmp_path / "e")], input=fa, capture_output=True, timeout=60)
+        assert r.returncode == 0, r.stderr
+        assert (tmp_path / "e_1.fa").read_bytes() == one and (tmp_path / "e_2.fa").read_bytes() == two
+    big = b"ACGT" * 3_000_000                      # 12 MB lines: longer than either tool's buffer
+    fa = b">x\n" + big + b"\n>y\n" + big[:-1] + b"\n"
+    r = subprocess.run([split, str(tmp_path / "l")], input=fa, capture_output=True, timeout=60)
+    assert r.returncode == 0 and (tmp_path / "l_1.fa").read_bytes() == b">x\n" + big + b"\n"
+    assert (tmp_path / "l_2.fa").read_bytes() == b">y\n" + big[:-1] + b"\n"
+    (tmp_path / "m1").write_bytes(b"@x\n" + big + b"\n+\n" + b"I" * len(big))        # no final newline
+    (tmp_path / "m2").write_bytes(b">y\n" + big[:100] + b"\n" + big[:50])
+    r = subprocess.run([merge, str(tmp_path / "m1"), str(tmp_path / "m2")], capture_output=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == b"@x\n" + big + b"\n+\n" + b"I" * len(big) + b"\n@y\n" + big[:150] + b"\n+\n" + b"*" * 150 + b"\n"
+    (tmp_path / "t1").write_bytes(b"@x\nACGT\n")
+    (tmp_path / "t2").write_bytes(b"@y\nACGT\n+\nIII\n@z\nA\n+\nI\n")
+    r = subprocess.run([merge, str(tmp_path / "t1"), str(tmp_path / "t1")], capture_output=True, timeout=60)
+    assert r.returncode == 134 and b"Truncated fastq file" in r.stderr
+    r = subprocess.run([merge, str(tmp_path / "t2"), str(tmp_path / "t2")], capture_output=True, timeout=60)
+    assert r.returncode == 134 and b"wrong number of quals" in r.stderr
+    r = subprocess.run([merge, str(tmp_path / "m2"), str(tmp_path / "missing")], capture_output=True, timeout=60)
+    assert r.returncode == 134 and b"Can't open file" in r.stderr
