@@ -209,7 +209,7 @@ def main():
         # PMC traffic (FETCH_SIZE x2 + WRITE_SIZE, separate passes: tools/profile_bench.sh) of all kernels of one step
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if world == 1 and os.path.exists(pmc):
+        if world == 1 and workload == "c1" and not pipe and not args.reads and os.path.exists(pmc):   # measured on this workload only
             try:
                 traffic = json.load(open(pmc)).get("whole_step_hbm_bytes")
             except Exception:
