@@ -8,6 +8,7 @@ import os
 import re
 import subprocess
 
+import numpy as np
 import pytest
 
 import quorum_amd
@@ -217,3 +218,83 @@ def test_mate_pair_helpers_edges(tmp_path):
     assert r.returncode == 134 and b"wrong number of quals" in r.stderr
     r = subprocess.run([merge, str(tmp_path / "m2"), str(tmp_path / "missing")], capture_output=True, timeout=60)
     assert r.returncode == 134 and b"Can't open file" in r.stderr
+
+
+def _model_parse(data):
+    """the reader of merge_mate_pairs restated: FASTA / FASTQ, multi-line sequences and qualities re-flowed"""
+    lines = data.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    out, i = [], 0
+    while i < len(lines):
+        if lines[i].startswith(b">"):
+            h, i, seq = lines[i][1:], i + 1, b""
+            while i < len(lines) and not lines[i].startswith(b">"):
+                seq += lines[i]
+                i += 1
+            out.append((h, seq, None))
+        else:
+            assert lines[i].startswith(b"@")
+            h, i, seq, qual = lines[i][1:], i + 1, b"", b""
+            while i < len(lines) and not lines[i].startswith(b"+"):
+                seq += lines[i]
+                i += 1
+            i += 1
+            while len(qual) < len(seq) and i < len(lines):
+                qual += lines[i]
+                i += 1
+            assert len(qual) == len(seq)
+            out.append((h, seq, qual))
+    return out
+
+
+def test_merge_mate_pairs_random_mixes(tmp_path):
+    """strict records (the reader's copy-free path), multi-line records, FASTA records, separator lines with text and
+    quality lines that start with '@' or '+', in random order and with or without a final newline: the tool's output
+    equals the restated reader's, record by record, for buffers of both streams that end anywhere"""
+    import subprocess
+    merge = os.path.join(ROOT, "quorum_amd", "bin", "merge_mate_pairs")
+    rng = np.random.default_rng(8)
+
+    def rand_file(n):
+        parts = []
+        fasta_only = rng.random() < 0.2
+        for i in range(n):
+            L = int(rng.integers(1, 300))
+            seq = bytes(rng.choice(list(b"ACGTN"), size=L).tolist())
+            kind = rng.random()
+            if fasta_only:
+                w = int(rng.integers(1, L + 1))
+                parts.append(b">f%d\n" % i + b"\n".join(seq[j:j + w] for j in range(0, L, w)) + b"\n")
+                continue
+            qual = bytes(rng.choice(list(b"@+I#5"), size=L).tolist())
+            plus = b"+" + (b"x%d" % i if rng.random() < 0.3 else b"")
+            if kind < 0.8:
+                parts.append(b"@r%d some text\n%s\n%s\n%s\n" % (i, seq, plus, qual))
+            else:  # multi-line: the quality pieces must not start a line with '@' before the count is reached
+                w = int(rng.integers(1, L + 1))
+                sl = b"\n".join(seq[j:j + w] for j in range(0, L, w))
+                ql = b"\n".join(qual[j:j + w] for j in range(0, L, w))
+                parts.append(b"@m%d\n%s\n%s\n%s\n" % (i, sl, plus, ql))
+        data = b"".join(parts)
+        return data[:-1] if rng.random() < 0.5 else data
+
+    for rep in range(6):
+        n = int(rng.integers(1, 400))
+        d1, d2 = rand_file(n), rand_file(n)
+        (tmp_path / "x1").write_bytes(d1)
+        (tmp_path / "x2").write_bytes(d2)
+        r = subprocess.run([merge, str(tmp_path / "x1"), str(tmp_path / "x2")], capture_output=True, timeout=60)
+        assert r.returncode == 0, r.stderr
+        want = b""
+        for a, b in zip(_model_parse(d1), _model_parse(d2)):
+            for h, s, q in (a, b):
+                want += b"@" + h + b"\n" + s + b"\n+\n" + (q if q is not None else b"*" * len(s)) + b"\n"
+        assert r.stdout == want, rep
+    # a large strict input crosses the 4 MiB buffer many times
+    big = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, b"ACGT" * 25, b"I" * 100) for i in range(60000))
+    (tmp_path / "b1").write_bytes(big)
+    (tmp_path / "b2").write_bytes(big[:-1])
+    r = subprocess.run([merge, str(tmp_path / "b1"), str(tmp_path / "b2")], capture_output=True, timeout=60)
+    recs = big.split(b"@")[1:]
+    assert r.returncode == 0 and r.stdout == b"".join(b"@" + x + b"@" + x for x in recs)
