@@ -295,6 +295,7 @@ int main(int argc, char* argv[]) {
   if (fa_fd < 0) die("Failed to open file '" + fa_name + "': " + strerror(errno));
 
   vlog("Correcting reads");
+  (void)fcntl(fa_fd, F_SETPIPE_SZ, 1 << 20);  // when the corrected reads go down a pipe (split_mate_pairs)
   const char* cb = getenv("QUORUM_HIP_CHUNK_MB");
   const size_t chunk_bytes = (cb && atol(cb) > 0 ? (size_t)atol(cb) : 256) << 20;
   char* buf = nullptr;
@@ -311,14 +312,31 @@ int main(int argc, char* argv[]) {
   auto join_writer = [&]() { if (writer.joinable()) writer.join(); };
   // (appending through a shared mapping filled by eight threads, which pays for the database file, was measured here
   // and gains nothing over write(): the pieces are 150 MB and the loop already hides most of the write)
-  for (const char* path : args.sequence) {
-    const int fd = !strcmp(path, "-") || !strcmp(path, "/dev/fd/0") ? 0 : open(path, O_RDONLY);
-    if (fd < 0) die(std::string("Can't open file '") + path + "'");
-    size_t have = 0;
-    bool eof = false;
-    struct stat fst;
-    const bool regular = fd != 0 && fstat(fd, &fst) == 0 && S_ISREG(fst.st_mode);
-    off_t fpos = 0;
+  // one chunk through the corrector; its text goes to the writer thread. Returns the bytes that formed whole records.
+  auto process = [&](const char* chunk, size_t have, bool eof) -> size_t {
+    size_t used = 0;
+    const double t1 = secs();
+    if (qh_corrector_correct_fastq(ec, chunk, have, eof, &used) != QH_OK) die(qh_last_error());
+    const char *fa, *lg;
+    size_t nfa, nlg;
+    qh_correct_stats st;
+    if (qh_corrector_fetch(ec, &fa, &nfa, &lg, &nlg, &st) != QH_OK) die(qh_last_error());
+    const double t2 = secs();
+    join_writer();  // chunk i-1 is out: its buffers are the ones the next fetch reuses
+    writer = std::thread([=, &fa_name, &log_name]() {
+      write_all(fa_fd, fa, nfa, fa_name);
+      write_all(log_fd, lg, nlg, log_name);
+    });
+    t_correct += t2 - t1;
+    t_write += secs() - t2;
+    total.reads += st.reads; total.corrected += st.corrected; total.skipped += st.skipped;
+    total.substitutions += st.substitutions; total.truncations += st.truncations;
+    total.bases_in += st.bases_in; total.bases_out += st.bases_out;
+    return used;
+  };
+  // The plain loop: read a chunk, correct it, carry the partial record at its end over. `have` bytes of the file are
+  // already in buf (the pipe loop below hands over to it when a record outgrows its buffers).
+  auto run_serial = [&](int fd, bool regular, off_t fpos, size_t have, bool eof, const char* path) {
     while (!eof || have) {
       if (!eof && have < cap) {
         const double t0 = secs();
@@ -328,24 +346,7 @@ int main(int argc, char* argv[]) {
         if (r < want) eof = true;
       }
       if (have == 0) break;
-      size_t used = 0;
-      const double t1 = secs();
-      if (qh_corrector_correct_fastq(ec, buf, have, eof, &used) != QH_OK) die(qh_last_error());
-      const char *fa, *lg;
-      size_t nfa, nlg;
-      qh_correct_stats st;
-      if (qh_corrector_fetch(ec, &fa, &nfa, &lg, &nlg, &st) != QH_OK) die(qh_last_error());
-      const double t2 = secs();
-      join_writer();  // chunk i-1 is out: its buffers are the ones the next fetch reuses
-      writer = std::thread([=, &fa_name, &log_name]() {
-        write_all(fa_fd, fa, nfa, fa_name);
-        write_all(log_fd, lg, nlg, log_name);
-      });
-      t_correct += t2 - t1;
-      t_write += secs() - t2;
-      total.reads += st.reads; total.corrected += st.corrected; total.skipped += st.skipped;
-      total.substitutions += st.substitutions; total.truncations += st.truncations;
-      total.bases_in += st.bases_in; total.bases_out += st.bases_out;
+      const size_t used = process(buf, have, eof);
       if (used == 0) {
         if (eof) die(std::string("Truncated fastq file '") + path + "'");
         // a record longer than the buffer: grow it
@@ -362,6 +363,88 @@ int main(int argc, char* argv[]) {
       memmove(buf, buf + used, have - used);
       have -= used;
     }
+  };
+  // A pipe (the paired-end plumbing, zcat | ...) delivers at the pace of its writer: a second thread fills the next
+  // chunk's buffer while this one corrects. Two buffers with `head` spare bytes in front, where the partial record of
+  // the previous chunk is put before the new bytes; a record that outgrows that goes back to the plain loop.
+  auto run_piped = [&](int fd, const char* path) {
+    (void)fcntl(fd, F_SETPIPE_SZ, 1 << 20);  // a pipe: fewer, larger transfers (no-op on anything else)
+    const size_t head = cap / 4 < ((size_t)16 << 20) ? cap / 4 : ((size_t)16 << 20);
+    char* pb[2] = {nullptr, nullptr};
+    bool ppinned[2] = {false, false};
+    for (int i = 0; i < 2; ++i) {
+      ppinned[i] = qh_host_alloc((void**)&pb[i], head + cap) == QH_OK;
+      if (!ppinned[i]) pb[i] = (char*)malloc(head + cap);
+      if (!pb[i]) die("out of memory for the chunk buffer");
+    }
+    struct fill_t { size_t n; bool eof; };
+    fill_t got[2] = {{0, false}, {0, false}};
+    std::thread reader;
+    auto start_read = [&](int j) {
+      reader = std::thread([&, j]() {
+        off_t unused = 0;
+        const size_t r = read_some(fd, false, &unused, pb[j] + head, cap);
+        got[j] = fill_t{r, r < cap};
+      });
+    };
+    start_read(0);
+    size_t tail = 0;
+    int j = 0;
+    bool handed_over = false;
+    for (;;) {
+      const double t0 = secs();
+      reader.join();
+      t_read += secs() - t0;
+      const fill_t f = got[j];
+      char* chunk = pb[j] + head - tail;
+      size_t have = tail + f.n;
+      if (!f.eof) start_read(j ^ 1);
+      if (have == 0) break;
+      size_t used = process(chunk, have, f.eof);
+      if (f.eof) {
+        // what a final chunk leaves is an error of the input; the corrector names it when asked about the rest alone
+        while (used < have) {
+          if (used == 0) die(std::string("Truncated fastq file '") + path + "'");
+          chunk += used; have -= used;
+          used = process(chunk, have, true);
+        }
+        break;
+      }
+      tail = have - used;
+      if (used == 0 || tail > head) {
+        // a record longer than a buffer's spare room: everything read so far into one growing buffer, plain loop from here
+        reader.join();
+        const fill_t g = got[j ^ 1];
+        const size_t need = tail + g.n;
+        if (need > cap) {
+          char* nb = nullptr;
+          const size_t ncap = need > cap * 2 ? need : cap * 2;
+          bool npinned = qh_host_alloc((void**)&nb, ncap) == QH_OK;
+          if (!npinned) nb = (char*)malloc(ncap);
+          if (!nb) die("out of memory for the chunk buffer");
+          if (pinned) qh_host_free(buf); else free(buf);
+          buf = nb; cap = ncap; pinned = npinned;
+        }
+        memcpy(buf, chunk + used, tail);
+        memcpy(buf + tail, pb[j ^ 1] + head, g.n);
+        for (int i = 0; i < 2; ++i) { if (ppinned[i]) qh_host_free(pb[i]); else free(pb[i]); }
+        run_serial(fd, false, 0, need, g.eof, path);
+        handed_over = true;
+        break;
+      }
+      memcpy(pb[j ^ 1] + head - tail, chunk + used, tail);  // in front of what the reader is bringing
+      j ^= 1;
+    }
+    if (!handed_over)
+      for (int i = 0; i < 2; ++i) { if (ppinned[i]) qh_host_free(pb[i]); else free(pb[i]); }
+  };
+  for (const char* path : args.sequence) {
+    const int fd = !strcmp(path, "-") || !strcmp(path, "/dev/fd/0") ? 0 : open(path, O_RDONLY);
+    if (fd < 0) die(std::string("Can't open file '") + path + "'");
+    struct stat fst;
+    const bool regular = fd != 0 && fstat(fd, &fst) == 0 && S_ISREG(fst.st_mode);
+    if (regular || getenv("QUORUM_HIP_NO_READ_AHEAD")) run_serial(fd, regular, 0, 0, false, path);
+    else run_piped(fd, path);
     if (fd != 0) close(fd);
   }
   { const double t0 = secs(); join_writer(); t_write += secs() - t0; }

@@ -188,6 +188,7 @@ int main(int argc, char* argv[]) {
   if (files.size() % 2 != 0) { fprintf(stderr, "Error: Must give a even number files\n"); return 1; }
   std::vector<const char*> even, odd;
   for (size_t i = 0; i < files.size(); ++i) (i % 2 ? odd : even).push_back(files[i]);
+  (void)fcntl(1, F_SETPIPE_SZ, 1 << 20);  // into a pipe, normally: fewer, larger transfers
   try {
     stream es(even), os(odd);
     record e, o;

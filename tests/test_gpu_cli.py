@@ -286,3 +286,43 @@ def test_sharded_cli_strict_input_never_takes_the_host_parser(tmp_path):
     m, v = sorted_pairs(*q.dump())
     assert m.size == om.size and (m == om).all() and (v == ov).all()
     q.close()
+
+
+def test_corrector_piped_input_equals_file_input(tmp_path):
+    """quorum_error_correct_reads reading a pipe (a second thread reads ahead into the next chunk's buffer) writes what it
+    writes for the same bytes in a file: many small chunks with records cut at their ends, multi-line records, a read
+    far longer than a buffer's spare room (the loop hands over to the plain one), and a truncated stream's error"""
+    k, bits = 24, 7
+    g = synth.make_genome(30000, seed=71)
+    fq = synth.make_fastq(g, 14000, 100, seed=72, tails=True).tobytes()
+    lines = fq.split(b"\n")
+    multi = []
+    for i in range(0, 4 * 3000, 4):          # the first 3000 records in multi-line form
+        multi += [lines[i], lines[i + 1][:33], lines[i + 1][33:], b"+", lines[i + 3][:50], lines[i + 3][50:]]
+    long_seq = bytes(synth._BASES[synth.make_genome(700000, seed=73)].tolist())
+    long_rec = b"@long\n" + long_seq + b"\n+\n" + b"I" * len(long_seq) + b"\n"
+    half = 7000 * synth.record_bytes(100)
+    texts = {"strict": fq, "multi": b"\n".join(multi) + b"\n" + fq[half:], "long": fq[:half] + long_rec + fq[half:]}
+    (tmp_path / "db.fastq").write_bytes(fq)
+    dbf = str(tmp_path / "db.jf")
+    r = subprocess.run([os.path.join(BIN, "quorum_create_database"), "-s", "1M", "-m", str(k), "-b", str(bits), "-q", "38",
+                        "-o", dbf, str(tmp_path / "db.fastq")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    ec = os.path.join(BIN, "quorum_error_correct_reads")
+    env = dict(os.environ, QUORUM_HIP_CHUNK_MB="1")
+    for name, text in texts.items():
+        (tmp_path / "in.fastq").write_bytes(text)
+        rf = subprocess.run([ec, "-d", "-p", "4", dbf, str(tmp_path / "in.fastq")], capture_output=True, timeout=300, env=env)
+        assert rf.returncode == 0, rf.stderr[-500:]
+        rp = subprocess.run([ec, "-d", "-p", "4", dbf, "/dev/fd/0"], input=text, capture_output=True, timeout=300, env=env)
+        assert rp.returncode == 0, rp.stderr[-500:]
+        assert rp.stdout == rf.stdout and rp.stderr == rf.stderr, name
+        assert sum(l.startswith(b">") for l in rp.stdout.split(b"\n")) == {"strict": 14000, "multi": 10000, "long": 14001}[name]
+        rs = subprocess.run([ec, "-d", "-p", "4", dbf, "/dev/fd/0"], input=text, capture_output=True, timeout=300,
+                            env=dict(env, QUORUM_HIP_NO_READ_AHEAD="1"))
+        assert rs.returncode == 0 and rs.stdout == rf.stdout and rs.stderr == rf.stderr, name
+    cut = fq[:len(fq) - 57]
+    rp = subprocess.run([ec, "-d", "-p", "4", dbf, "/dev/fd/0"], input=cut, capture_output=True, timeout=300, env=env)
+    (tmp_path / "in.fastq").write_bytes(cut)
+    rf = subprocess.run([ec, "-d", "-p", "4", dbf, str(tmp_path / "in.fastq")], capture_output=True, timeout=300, env=env)
+    assert rp.returncode != 0 and rf.returncode != 0 and rp.stderr[-200:] == rf.stderr[-200:]
