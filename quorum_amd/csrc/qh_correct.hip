@@ -97,11 +97,14 @@ __device__ __forceinline__ uint64_t ec_hash(const ec_mer& m, int k) {
 }
 __device__ __forceinline__ uint32_t ec_code0(const ec_mer& m) { return (m.a0 & 1u) | ((m.a1 & 1u) << 1); }
 
-// NARROW: the value field and the remainder + probe fields each fit 32 bits (k = 24 at genome-size
-// tables): counts and tag compares are 32-bit. Otherwise everything is 64-bit.
-template <bool NARROW> struct ec_word;
-template <> struct ec_word<true> { typedef uint32_t type; };
-template <> struct ec_word<false> { typedef uint64_t type; };
+// WM, the word mode of a kernel: 0 = the value field and the remainder + probe fields (the tag) each fit 32 bits
+// (k = 24 at genome-size tables): counts and tag compares are 32-bit; 1 = 64-bit tags, 32-bit values (k = 31, and
+// every run with a contaminant set, whose small table has long tags): a slot is 64 bits, so a tag of more than 32
+// bits leaves a value of fewer; 2 = everything 64-bit (a value field of more than 32 bits: -b above 31).
+template <int WM> struct ec_tagw { typedef uint64_t type; };
+template <> struct ec_tagw<0> { typedef uint32_t type; };
+template <int WM> struct ec_valw { typedef uint32_t type; };
+template <> struct ec_valw<2> { typedef uint64_t type; };
 
 // database_query::operator[] for N hashed mers at once. Probing is linear inside a 2^wbits-slot
 // window, so consecutive probes are consecutive words: every round loads the 64-byte line of eight
@@ -115,10 +118,11 @@ template <> struct ec_word<false> { typedef uint64_t type; };
 #define EC_GROUP 8
 struct ec_group { uint64_t s[EC_GROUP]; };
 
-template <int N, bool NARROW>
+template <int N, int WM>
 __device__ __forceinline__ void ec_lookup_wide(const qh_geom& g, const uint64_t* __restrict__ table,
-                                               const uint64_t (&h)[N], typename ec_word<NARROW>::type (&v)[N]) {
-  typedef typename ec_word<NARROW>::type W;
+                                               const uint64_t (&h)[N], typename ec_valw<WM>::type (&v)[N]) {
+  typedef typename ec_tagw<WM>::type W;   // tags
+  typedef typename ec_valw<WM>::type V;   // values
   const uint32_t wmask = (1u << g.wbits) - 1u;
   uint64_t gaddr[N];  // slot index of the group's first slot
   W tag0[N];
@@ -147,7 +151,7 @@ __device__ __forceinline__ void ec_lookup_wide(const qh_geom& g, const uint64_t*
         const uint64_t sj = grp[n].s[j];
         if (pend[n] && idx >= 0) {
           if (idx > g.max_reprobe || sj == 0) pend[n] = false;
-          else if ((W)(sj >> g.vbits) == (tag0[n] | (W)(idx + 1))) { v[n] = (W)sj & (W)g.vmask; pend[n] = false; }
+          else if ((W)(sj >> g.vbits) == (tag0[n] | (W)(idx + 1))) { v[n] = (V)sj & (V)g.vmask; pend[n] = false; }
         }
       }
       if (pend[n]) {  // next group of the window (wraps at the window's end)
@@ -177,14 +181,14 @@ __device__ __forceinline__ uint64_t ec_lookup_narrow_table(const qh_geom& g, con
   return 0;
 }
 
-template <bool NARROW>
-__device__ __forceinline__ typename ec_word<NARROW>::type ec_lookup(const qh_geom& g, const uint64_t* __restrict__ table,
-                                                                     uint64_t h) {
-  typedef typename ec_word<NARROW>::type W;
-  if (g.wbits < 3) return (W)ec_lookup_narrow_table(g, table, h);
+template <int WM>
+__device__ __forceinline__ typename ec_valw<WM>::type ec_lookup(const qh_geom& g, const uint64_t* __restrict__ table,
+                                                                uint64_t h) {
+  typedef typename ec_valw<WM>::type V;
+  if (g.wbits < 3) return (V)ec_lookup_narrow_table(g, table, h);
   const uint64_t hh[1] = {h};
-  W v[1];
-  ec_lookup_wide<1, NARROW>(g, table, hh, v);
+  V v[1];
+  ec_lookup_wide<1, WM>(g, table, hh, v);
   return v[0];
 }
 
@@ -195,10 +199,11 @@ __device__ __forceinline__ typename ec_word<NARROW>::type ec_lookup(const qh_geo
 // slot with the four tags; it ends when all four are found, at the first empty slot (whatever is still
 // missing is absent) or at the reprobe limit -- exactly where the four separate walks would end.
 // Needs lsize + shard_bits <= 2(k-2) (the home must not depend on the end bases) and wbits >= 3.
-template <bool NARROW>
+template <int WM>
 __device__ __forceinline__ void ec_lookup_siblings(const qh_geom& g, const uint64_t* __restrict__ table, const ec_mer& m,
-                                                   typename ec_word<NARROW>::type (&w)[4]) {
-  typedef typename ec_word<NARROW>::type W;
+                                                   typename ec_valw<WM>::type (&w)[4]) {
+  typedef typename ec_tagw<WM>::type W;   // tags
+  typedef typename ec_valw<WM>::type V;   // values
   const int k = g.k, kc = k - 2;
   const uint32_t cm = (1u << kc) - 1u;
   // the core both strands share, in its smaller orientation, and its hash: the siblings' common low bits
@@ -244,7 +249,7 @@ __device__ __forceinline__ void ec_lookup_siblings(const qh_geom& g, const uint6
       const bool valid = (uint32_t)(pi + j) <= span;
       stop |= valid && sj == 0;
       const W t = valid ? (W)(sj >> g.vbits) - (W)(pi + j + 1) : (W)1;
-      const W val = (W)sj & (W)g.vmask;
+      const V val = (V)sj & (V)g.vmask;
 #pragma unroll
       for (int y = 0; y < 4; ++y) w[y] = t == tag[y] ? val : w[y];
     }
@@ -259,15 +264,15 @@ __device__ __forceinline__ void ec_lookup_siblings(const qh_geom& g, const uint6
 // otherwise four lookups advancing together); the fold runs in the order of the forward strand's codes
 // like the upstream loop (the candidate with a-strand code y is the forward code y when d > 0 and
 // 3 - y when d < 0)
-template <bool NARROW, bool SIB>
+template <int WM, bool SIB>
 __device__ __forceinline__ int ec_best_alternatives(const qh_geom& g, const uint64_t* __restrict__ table,
-                                                    const ec_mer& m, int d, typename ec_word<NARROW>::type (&counts)[4],
+                                                    const ec_mer& m, int d, typename ec_valw<WM>::type (&counts)[4],
                                                     int* ucode, int* level) {
-  typedef typename ec_word<NARROW>::type W;
+  typedef typename ec_valw<WM>::type W;   // values only here
   const int k = g.k;
   W w[4];
   if (SIB) {
-    ec_lookup_siblings<NARROW>(g, table, m, w);
+    ec_lookup_siblings<WM>(g, table, m, w);
   } else {
     uint64_t h[4];
 #pragma unroll
@@ -280,7 +285,7 @@ __device__ __forceinline__ int ec_best_alternatives(const qh_geom& g, const uint
 #pragma unroll
       for (int y = 0; y < 4; ++y) w[y] = (W)ec_lookup_narrow_table(g, table, h[y]);
     } else {
-      ec_lookup_wide<4, NARROW>(g, table, h, w);
+      ec_lookup_wide<4, WM>(g, table, h, w);
     }
   }
   int count = 0, lvl = 0;
@@ -314,13 +319,13 @@ __device__ __forceinline__ W ec_sel4(const W (&c)[4], int i) {
 
 // database_query::get_best_alternatives batched (qh_query_best_alternatives_batch): a mer per lane, the
 // four siblings in one walk. fmers are 2-bit packed forward mers; backward[i] selects backward_mer.
-template <bool NARROW>
+template <int WM>
 __global__ __launch_bounds__(256) void k_best_alternatives_sib(const uint64_t* __restrict__ table, const qh_geom g,
                                                                const uint64_t* __restrict__ fmers,
                                                                const uint8_t* __restrict__ backward, uint64_t n,
                                                                uint64_t* __restrict__ counts, int32_t* __restrict__ ucode,
                                                                int32_t* __restrict__ level, int32_t* __restrict__ nkept) {
-  typedef typename ec_word<NARROW>::type W;
+  typedef typename ec_valw<WM>::type W;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t pk = qh_pkey(fmers[i] & g.kmask, g.k);
     const uint32_t km = (uint32_t)((1ull << g.k) - 1);
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(256) void k_best_alternatives_sib(const uint64_t* _
     const ec_mer m = d > 0 ? ec_mer{f0, f1, r0, r1} : ec_mer{r0, r1, f0, f1};
     W c[4];
     int uc = 0, lvl = 0;
-    const int cnt = ec_best_alternatives<NARROW, true>(g, table, m, d, c, &uc, &lvl);
+    const int cnt = ec_best_alternatives<WM, true>(g, table, m, d, c, &uc, &lvl);
 #pragma unroll
     for (int a = 0; a < 4; ++a) counts[i * 4 + a] = c[a];
     ucode[i] = uc; level[i] = lvl; nkept[i] = cnt;
@@ -349,10 +354,13 @@ void qh_launch_best_alternatives(const uint64_t* table, const qh_geom& g, const 
   uint64_t blocks = (n + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   if (g.vbits <= 32 && g.rbits + g.pbits <= 32)
-    hipLaunchKernelGGL(k_best_alternatives_sib<true>, dim3((unsigned)blocks), dim3(256), 0, s, table, g, fmers, backward, n,
+    hipLaunchKernelGGL(k_best_alternatives_sib<0>, dim3((unsigned)blocks), dim3(256), 0, s, table, g, fmers, backward, n,
+                       counts, ucode, level, nkept);
+  else if (g.vbits <= 32)
+    hipLaunchKernelGGL(k_best_alternatives_sib<1>, dim3((unsigned)blocks), dim3(256), 0, s, table, g, fmers, backward, n,
                        counts, ucode, level, nkept);
   else
-    hipLaunchKernelGGL(k_best_alternatives_sib<false>, dim3((unsigned)blocks), dim3(256), 0, s, table, g, fmers, backward, n,
+    hipLaunchKernelGGL(k_best_alternatives_sib<2>, dim3((unsigned)blocks), dim3(256), 0, s, table, g, fmers, backward, n,
                        counts, ucode, level, nkept);
 }
 
@@ -449,10 +457,10 @@ __device__ __forceinline__ uint32_t ec_error_text_bytes(uint32_t status) {
 // ------------------------------------------------------------------ the corrector
 
 // check_contaminant (error_correct_reads.cc:346-357)
-template <bool NARROW>
+template <int WM>
 __device__ __forceinline__ int ec_check_contaminant(const qh_ec_dev& P, const uint64_t* __restrict__ ctable, const ec_mer& m,
                                                     ec_log& log, int cpos) {
-  if (ctable && ec_lookup<NARROW>(P.cg, ctable, ec_hash(m, P.g.k)) != 0) {
+  if (ctable && ec_lookup<WM>(P.cg, ctable, ec_hash(m, P.g.k)) != 0) {
     if (P.trim_contaminant) { ec_truncation(log, cpos, P.window, P.error); return EC_TRUNCATE; }
     return EC_ERROR;
   }
@@ -460,12 +468,12 @@ __device__ __forceinline__ int ec_check_contaminant(const qh_ec_dev& P, const ui
 }
 
 // log_substitution (error_correct_reads.cc:360-379); from / to are codes of the forward strand
-template <bool NARROW>
+template <int WM>
 __device__ __forceinline__ int ec_log_substitution(const qh_ec_dev& P, const uint64_t* __restrict__ ctable, ec_mer& m, int d,
                                                    int& out, ec_log& log, int cpos, int from, int to) {
   if (from == to) return EC_OK;
   ec_replace0(m, P.g.k, (uint32_t)(d > 0 ? to : 3 - to));
-  const int cc = ec_check_contaminant<NARROW>(P, ctable, m, log, cpos);
+  const int cc = ec_check_contaminant<WM>(P, ctable, m, log, cpos);
   if (cc != EC_OK) return cc;
   const uint32_t entry = (uint32_t)cpos | ((uint32_t)(from >= 0 ? from : 4) << 25) | ((uint32_t)(to >= 0 ? to : 4) << 28);
   if (ec_push(log, entry, P.window, P.error)) {
@@ -524,7 +532,7 @@ __device__ __forceinline__ void ec_write(ec_wbuf& b, uint8_t* __restrict__ obuf,
   b.mask |= 1u << (off & 15u);
 }
 
-template <bool NARROW, bool SIB>
+template <int WM, bool SIB>
 __global__ __launch_bounds__(EC_BLOCK) __attribute__((amdgpu_waves_per_eu(EC_WAVES, EC_WAVES))) void k_correct_reads(const uint8_t* __restrict__ buf, size_t buf_len,
                                                             const uint4* __restrict__ recs,
                                                             const uint2* __restrict__ hdr,
@@ -536,7 +544,7 @@ __global__ __launch_bounds__(EC_BLOCK) __attribute__((amdgpu_waves_per_eu(EC_WAV
                                                             uint8_t* __restrict__ obuf, uint32_t* __restrict__ logs,
                                                             uint32_t* __restrict__ res,
                                                             qh_ec_totals* __restrict__ tot) {
-  typedef typename ec_word<NARROW>::type W;
+  typedef typename ec_valw<WM>::type W;   // values and counts; tags stay inside the lookups
   if (meta->format_err) return;
   const qh_ec_dev& P = *Pp;
   const uint32_t nrec = meta->nrec;
@@ -581,10 +589,10 @@ __global__ __launch_bounds__(EC_BLOCK) __attribute__((amdgpu_waves_per_eu(EC_WAV
       int found = 0;
       while (in < len) {
         const uint64_t h = ec_hash(mer, k);
-        const bool contaminated = ctable && ec_lookup<NARROW>(P.cg, ctable, h) != 0;
+        const bool contaminated = ctable && ec_lookup<WM>(P.cg, ctable, h) != 0;
         if (contaminated && !P.trim_contaminant) { status = EC_ST_CONTAMINANT; break; }
         if (!contaminated) {
-          const W v = ec_lookup<NARROW>(P.g, table, h);
+          const W v = ec_lookup<WM>(P.g, table, h);
           const W val = (v & 1) ? v >> 1 : 0;  // get_val
           found = (int)val >= P.anchor ? found + 1 : 0;
           if (found >= P.good) { anchored = true; break; }
@@ -607,7 +615,7 @@ __global__ __launch_bounds__(EC_BLOCK) __attribute__((amdgpu_waves_per_eu(EC_WAV
       const int start_off = in;
       uint32_t prev0;
       {
-        const W v = ec_lookup<NARROW>(P.g, table, ec_hash(mer, k));
+        const W v = ec_lookup<WM>(P.g, table, ec_hash(mer, k));
         prev0 = (uint32_t)((v & 1) ? v >> 1 : 0);
       }
       int d = +1;
@@ -640,7 +648,7 @@ __global__ __launch_bounds__(EC_BLOCK) __attribute__((amdgpu_waves_per_eu(EC_WAV
             const uint32_t x = ori_code >= 0 ? (uint32_t)ori_code : 0u;
             ec_shift(mer, k, km, d > 0 ? x : 3u - x);
             if (ori_code >= 0 && ctable) {
-              const int cc = ec_check_contaminant<NARROW>(P, ctable, mer, log, cpos);
+              const int cc = ec_check_contaminant<WM>(P, ctable, mer, log, cpos);
               if (cc == EC_TRUNCATE) fin = true;
               else if (cc == EC_ERROR) { status = EC_ST_CONTAMINANT; break; }
             }
@@ -657,7 +665,7 @@ __global__ __launch_bounds__(EC_BLOCK) __attribute__((amdgpu_waves_per_eu(EC_WAV
         const bool stepping = lookup || fin;  // an iteration that works on a base (fin: cut short before its lookup)
         W counts[4] = {0, 0, 0, 0};
         int ucode = 0, level = 0, count = 0;
-        if (lookup) count = ec_best_alternatives<NARROW, SIB>(P.g, table, lm, d, counts, &ucode, &level);
+        if (lookup) count = ec_best_alternatives<WM, SIB>(P.g, table, lm, d, counts, &ucode, &level);
         if (lookup && in_cont) {
           check_code = cur_i;
           if (count > 0 && level >= s_level) {  // :502-506
@@ -675,7 +683,7 @@ __global__ __launch_bounds__(EC_BLOCK) __attribute__((amdgpu_waves_per_eu(EC_WAV
             fin = true;
           } else if (count == 1) {  // one continuation: a substitution
             prev_count = (uint32_t)ec_sel4(counts, ucode);
-            const int lc = ec_log_substitution<NARROW>(P, ctable, mer, d, out, log, cpos, ori_code, ucode);
+            const int lc = ec_log_substitution<WM>(P, ctable, mer, d, out, log, cpos, ori_code, ucode);
             if (lc == EC_TRUNCATE) fin = true;
             else if (lc == EC_ERROR) { status = EC_ST_CONTAMINANT; break; }
             else emit = true;
@@ -750,7 +758,7 @@ __global__ __launch_bounds__(EC_BLOCK) __attribute__((amdgpu_waves_per_eu(EC_WAV
             }
             if (ncand != 1) check_code = -1;
             if (check_code >= 0) {
-              const int lc = ec_log_substitution<NARROW>(P, ctable, mer, d, out, log, cpos, ori_code, check_code);
+              const int lc = ec_log_substitution<WM>(P, ctable, mer, d, out, log, cpos, ori_code, check_code);
               if (lc == EC_TRUNCATE) fin = true;
               else if (lc == EC_ERROR) { status = EC_ST_CONTAMINANT; break; }
             }
@@ -1072,7 +1080,7 @@ struct qh_corrector {
   qh_correct_params params;
   qh_ec_dev P;
   qh_ec_dev* d_P = nullptr;    // the same block in device memory (the kernel reads it through the scalar cache)
-  bool narrow = false;         // value and tag fields fit 32 bits: the 32-bit kernel
+  int word_mode = 2;           // 0: value and tag fields fit 32 bits; 1: 64-bit tags, 32-bit values; 2: all 64-bit
   bool siblings = false;       // the home slot does not depend on the end bases: one walk per get_best_alternatives
   uint32_t* d_ptab = nullptr;
   uint64_t* own_table = nullptr;  // the database re-hashed into a sparser table for the walks (corrector_init)
@@ -1197,7 +1205,9 @@ static int corrector_init(qh_corrector* c) {
   }
   const qh_geom& g = c->P.g;
   const qh_geom& cg = c->P.cg;
-  c->narrow = g.vbits <= 32 && g.rbits + g.pbits <= 32 && (!c->P.ctable || (cg.vbits <= 32 && cg.rbits + cg.pbits <= 32));
+  const bool val32 = g.vbits <= 32 && (!c->P.ctable || cg.vbits <= 32);
+  const bool tag32 = g.rbits + g.pbits <= 32 && (!c->P.ctable || cg.rbits + cg.pbits <= 32);
+  c->word_mode = val32 ? (tag32 ? 0 : 1) : 2;
   c->siblings = g.k >= 4 && g.wbits >= 3 && g.lsize + g.shard_bits <= 2 * (g.k - 2);
   QH_HIP(hipMalloc((void**)&c->d_P, sizeof(qh_ec_dev)));
   QH_HIP(hipMemcpy(c->d_P, &c->P, sizeof(qh_ec_dev), hipMemcpyHostToDevice));
@@ -1267,10 +1277,14 @@ static int enqueue_correct(qh_corrector* c, const uint8_t* dev_buf, size_t len, 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(EC_BLOCK), 0, c->stream, dev_buf, len, c->d_recs, d_hdr, c->d_meta, c->d_P,
                        c->P.table, c->P.ctable, c->P.ptab, c->d_obuf, c->d_logs, c->d_res, c->d_tot);
   };
-  if (c->narrow && c->siblings) launch(k_correct_reads<true, true>);
-  else if (c->narrow) launch(k_correct_reads<true, false>);
-  else if (c->siblings) launch(k_correct_reads<false, true>);
-  else launch(k_correct_reads<false, false>);
+  switch (c->word_mode * 2 + (c->siblings ? 1 : 0)) {
+    case 0: launch(k_correct_reads<0, false>); break;
+    case 1: launch(k_correct_reads<0, true>); break;
+    case 2: launch(k_correct_reads<1, false>); break;
+    case 3: launch(k_correct_reads<1, true>); break;
+    case 4: launch(k_correct_reads<2, false>); break;
+    default: launch(k_correct_reads<2, true>); break;
+  }
   QH_HIP(hipEventRecord(c->ev[2], c->stream));
   hipLaunchKernelGGL(k_ec_block_sums, dim3(nblocks ? nblocks : 1), dim3(EC_FMT_BLOCK), 0, c->stream, c->d_res, c->d_meta,
                      c->d_bsums);

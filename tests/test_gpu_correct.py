@@ -132,7 +132,7 @@ def test_switches(bacterial, kw):
     ec.close()
 
 
-@pytest.mark.parametrize("k,bits", [(15, 7), (31, 7), (24, 3), (20, 12)])
+@pytest.mark.parametrize("k,bits", [(15, 7), (31, 7), (24, 3), (20, 12), (12, 34), (10, 7)])  # (12, 34): values wider than 32 bits; (10, 7): no sibling walk
 def test_other_geometries(k, bits):
     g = synth.make_genome(20000, seed=k)
     fq = synth.make_fastq(g, 6000, 120, err=0.02, seed=k + 1, tails=True).tobytes()
