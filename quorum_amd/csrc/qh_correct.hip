@@ -49,6 +49,11 @@ struct qh_ec_dev {
   const uint64_t* table;
   qh_geom cg;
   const uint64_t* ctable;  // null: contaminant_no_database
+  // bit [h & cbits_mask] is set for the hash h of every contaminant k-mer (cbits_mask == 0: no such filter). A
+  // contaminant set is a few thousand k-mers and nearly every base of every read is not one of them: the
+  // bit answers that without the walk through the set's table (a 64-byte line and eight tag compares per base).
+  const uint32_t* cbits;
+  uint32_t cbits_mask;
   int skip, good, anchor, min_count, cutoff, window, error, qual_cutoff;
   int trim_contaminant, do_homo_trim, homo_trim, no_discard;
   // bit [c * ptab_stride + sum]: poisson_term(sum * collision_prob, c) < poisson_threshold, evaluated by the
@@ -456,11 +461,32 @@ __device__ __forceinline__ uint32_t ec_error_text_bytes(uint32_t status) {
 
 // ------------------------------------------------------------------ the corrector
 
+// is_contaminant (error_correct_reads.cc:692-708) for the hash of a canonical mer
+template <int WM>
+__device__ __forceinline__ bool ec_is_contaminant(const qh_ec_dev& P, const uint64_t* __restrict__ ctable, uint64_t h) {
+  if (P.cbits_mask) {
+    const uint32_t i = (uint32_t)h & P.cbits_mask;
+    if (!((P.cbits[i >> 5] >> (i & 31u)) & 1u)) return false;
+  }
+  return ec_lookup<WM>(P.cg, ctable, h) != 0;
+}
+
+__global__ __launch_bounds__(256) void k_ec_contaminant_bits(const uint64_t* __restrict__ ctable, const qh_geom cg, uint64_t nslots,
+                                                             uint32_t* __restrict__ bits, uint32_t mask) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t s = ctable[i];
+    if (s) {
+      const uint32_t b = (uint32_t)qh_slot_hash(cg, s, i) & mask;
+      atomicOr(&bits[b >> 5], 1u << (b & 31u));
+    }
+  }
+}
+
 // check_contaminant (error_correct_reads.cc:346-357)
 template <int WM>
 __device__ __forceinline__ int ec_check_contaminant(const qh_ec_dev& P, const uint64_t* __restrict__ ctable, const ec_mer& m,
                                                     ec_log& log, int cpos) {
-  if (ctable && ec_lookup<WM>(P.cg, ctable, ec_hash(m, P.g.k)) != 0) {
+  if (ctable && ec_is_contaminant<WM>(P, ctable, ec_hash(m, P.g.k))) {
     if (P.trim_contaminant) { ec_truncation(log, cpos, P.window, P.error); return EC_TRUNCATE; }
     return EC_ERROR;
   }
@@ -589,7 +615,7 @@ __global__ __launch_bounds__(EC_BLOCK) __attribute__((amdgpu_waves_per_eu(EC_WAV
       int found = 0;
       while (in < len) {
         const uint64_t h = ec_hash(mer, k);
-        const bool contaminated = ctable && ec_lookup<WM>(P.cg, ctable, h) != 0;
+        const bool contaminated = ctable && ec_is_contaminant<WM>(P, ctable, h);
         if (contaminated && !P.trim_contaminant) { status = EC_ST_CONTAMINANT; break; }
         if (!contaminated) {
           const W v = ec_lookup<WM>(P.g, table, h);
@@ -1080,6 +1106,7 @@ struct qh_corrector {
   qh_correct_params params;
   qh_ec_dev P;
   qh_ec_dev* d_P = nullptr;    // the same block in device memory (the kernel reads it through the scalar cache)
+  uint32_t* d_cbits = nullptr; // bit filter in front of the contaminant table (qh_ec_dev::cbits)
   int word_mode = 2;           // 0: value and tag fields fit 32 bits; 1: 64-bit tags, 32-bit values; 2: all 64-bit
   bool siblings = false;       // the home slot does not depend on the end bases: one walk per get_best_alternatives
   uint32_t* d_ptab = nullptr;
@@ -1127,7 +1154,7 @@ extern "C" void qh_corrector_destroy(qh_corrector* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* dptrs[] = {c->own_table, c->d_P, c->d_ptab, c->d_chunk, c->d_recs, c->d_hdr, c->d_tiles, c->d_nlplane, c->d_obuf, c->d_logs,
+  void* dptrs[] = {c->own_table, c->d_cbits, c->d_P, c->d_ptab, c->d_chunk, c->d_recs, c->d_hdr, c->d_tiles, c->d_nlplane, c->d_obuf, c->d_logs,
                    c->d_res, c->d_bsums, c->d_fa, c->d_log, c->d_meta, c->d_tot};
   for (void* p : dptrs) if (p) (void)hipFree(p);
   void* hptrs[] = {c->h_fa[0], c->h_fa[1], c->h_log[0], c->h_log[1], c->h_meta, c->h_tot};
@@ -1201,6 +1228,26 @@ static int corrector_init(qh_corrector* c) {
           (void)hipGetLastError();
         }
       }
+    }
+  }
+  if (c->P.ctable && !getenv("QH_EC_NO_CONTAMINANT_BITS")) {
+    // 2^22 bits (512 KiB, at home in the L2 cache): a set of a few thousand k-mers passes one base in a thousand on.
+    // (Taking the index from the core hash the sibling walk computes anyway, so that a base that passes is not
+    // hashed at all, was measured too: no gain over testing the bit after the hash.)
+    int b = 22;
+    if (b > 2 * c->P.cg.k) b = 2 * c->P.cg.k;
+    const size_t words = b > 5 ? (size_t)1 << (b - 5) : 1;
+    if (hipMalloc((void**)&c->d_cbits, words * 4) == hipSuccess) {
+      QH_HIP(hipMemsetAsync(c->d_cbits, 0, words * 4, c->stream));
+      const uint32_t mask = (uint32_t)(((uint64_t)1 << b) - 1);
+      hipLaunchKernelGGL(k_ec_contaminant_bits, dim3(256), dim3(256), 0, c->stream, c->P.ctable, c->P.cg,
+                         qh_table_slots(c->P.cg), c->d_cbits, mask);
+      QH_HIP(hipGetLastError());
+      QH_HIP(hipStreamSynchronize(c->stream));
+      c->P.cbits = c->d_cbits;
+      c->P.cbits_mask = mask;
+    } else {
+      (void)hipGetLastError();
     }
   }
   const qh_geom& g = c->P.g;

@@ -195,6 +195,37 @@ def test_contaminant(trim):
     gc.close(); q.close(); h.close(); odb.close(); oc.close()
 
 
+@pytest.mark.parametrize("k", [24, 9])
+def test_contaminant_bit_filter_changes_nothing(k, monkeypatch):
+    """the bit filter in front of the contaminant table (a bit per hash of a contaminant k-mer; 2^22 bits, fewer for
+    short mers) only ever answers "not a contaminant" for mers that are none: same text with and without it, and both
+    equal to the oracle's; at k = 9 the read's own k-mers collide with the adapters' all the time"""
+    rng = np.random.default_rng(13)
+    g = synth.make_genome(20000, seed=19)
+    fq = synth.make_fastq(g, 5000, 100, err=0.01, seed=20).tobytes()
+    adapters = [l.strip() for l in open(ADAPTERS, "rb").read().split(b"\n") if l and not l.startswith(b">")]
+    adapters = [a for a in adapters if len(a) >= 24]
+    recs = fq.split(b"\n")
+    for i in range(1, len(recs), 4):
+        if rng.random() < 0.05:
+            a = adapters[int(rng.integers(0, len(adapters)))]
+            at = int(rng.integers(0, 70))
+            s = bytearray(recs[i])
+            n = min(len(a), 100 - at)
+            s[at:at + n] = a[:n]
+            recs[i] = bytes(s)
+    fq = b"\n".join(recs)
+    odb, h, q = build_pair(fq, k)
+    oc = po.OracleDB(1 << 16, k, 1)
+    oc.add_fasta(open(ADAPTERS, "rb").read())
+    gc = qa.contaminant_database(ADAPTERS, k)
+    fa1, lg1, st1 = check_parity(odb, q, fq, ocont=oc, gcont=gc, trim_contaminant=True, cutoff=4)
+    monkeypatch.setenv("QH_EC_NO_CONTAMINANT_BITS", "1")
+    fa2, lg2, st2 = check_parity(odb, q, fq, ocont=oc, gcont=gc, trim_contaminant=True, cutoff=4)
+    assert fa1 == fa2 and lg1 == lg2 and st1 == st2 and st1["truncations"] > 100
+    gc.close(); q.close(); h.close(); odb.close(); oc.close()
+
+
 def test_config5_shape_k31_paired_tails_adapters():
     """BASELINE configs[4]: 150 bp reads, 3 % errors, low-quality tails, k = 31, adapters spliced at the 3' end
     of 1 % of the reads, contaminant set = data/adapter.fa, --trim-contaminant (64-bit tags: the wide kernel)"""

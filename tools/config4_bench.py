@@ -47,14 +47,18 @@ def main():
     ap.add_argument("--size", type=int, default=400_000_000)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--cpu-sample", type=int, default=20_000)
+    ap.add_argument("--err", type=float, default=0.03, help="substitution rate (parts of the configuration, for breakdowns)")
+    ap.add_argument("--no-contaminant", action="store_true")
+    ap.add_argument("--no-tails", action="store_true")
     a = ap.parse_args()
 
     import quorum_amd as qa
     from quorum_amd import synth
 
     g = synth.make_genome(a.genome, seed=51)
-    fq = synth.make_fastq(g, a.reads, L, err=0.03, seed=52, tails=True)
-    splice_adapters(fq, 0.01, 55)
+    fq = synth.make_fastq(g, a.reads, L, err=a.err, seed=52, tails=not a.no_tails)
+    if not a.no_contaminant:
+        splice_adapters(fq, 0.01, 55)
     chunk = torch.from_numpy(fq).cuda()
     torch.cuda.synchronize()
 
@@ -73,7 +77,7 @@ def main():
     st = h.done()
     ktimes = [h.kernel_time(i) for i in range(4)]
     q = h.as_query()
-    gc = qa.contaminant_database(ADAPTERS, K)
+    gc = None if a.no_contaminant else qa.contaminant_database(ADAPTERS, K)
     ec = qa.ErrorCorrector(q, contaminant=gc, trim_contaminant=True)
     ec.correct_device(chunk.data_ptr(), chunk.numel())
     torch.cuda.synchronize()
@@ -105,10 +109,12 @@ def main():
         ni = odb.add_fastq_ptr(fq.ctypes.data, fq.size, MIN_QUAL, min(16, os.cpu_count() or 1))
         t_build = time.perf_counter() - t0
         oc = po.OracleDB(1 << 16, K, 1)
-        oc.add_fasta(open(ADAPTERS, "rb").read())
+        if not a.no_contaminant:
+            oc.add_fasta(open(ADAPTERS, "rb").read())
         sample = fq[:n * synth.record_bytes(L)].tobytes()
         t0 = time.perf_counter()
-        ofa, olg, on = odb.correct_fastq(sample, po.ec_params(ec.cutoff, trim_contaminant=True), contaminant=oc)
+        ofa, olg, on = odb.correct_fastq(sample, po.ec_params(ec.cutoff, trim_contaminant=True),
+                                          contaminant=None if a.no_contaminant else oc)
         t_corr = time.perf_counter() - t0
         out["oracle"] = {"build_kmers_per_s": ni / t_build, "build_threads": min(16, os.cpu_count() or 1),
                          "correct_bases_per_s_one_thread": n * L / t_corr, "sample_reads": n,
