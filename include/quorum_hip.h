@@ -71,7 +71,9 @@ const char* qh_version(void);
 /* hash_with_quality::hash_with_quality(size, key_len=2k, bits, nb_threads, reprobe_limit)
  * (src/mer_database.hpp:78-87) together with the argument rules of
  * create_database main (src/create_database.cc:105-112): k in 1..31, bits in 1..63
- * (and small enough that remainder+probe+value fit one 64-bit slot), size is
+ * (where remainder + probe + value exceed one 64-bit slot -- large -b, long mers in small
+ * tables -- the values live in a side array of their own like upstream's val_array,
+ * mer_database.hpp:81: same content, same file format, direct global-CAS path only), size is
  * rounded up to a power of two like large_hash::array does, min_qual is the
  * threshold compared as a signed char (:48,:81,:110).  device = HIP device id.
  * shard_bits/shard_id: this handle owns shard `shard_id` of 2^shard_bits

@@ -7,7 +7,8 @@
 // table is full and cannot grow, every thread calls done(), open/parse failures throw
 // std::runtime_error. add() may be called concurrently (calls are batched under a mutex and
 // handed to the GPU a million at a time); the const methods of database_query are thread-safe and run
-// concurrently (the library gives every call a stream of its own).
+// concurrently (the library gives every call a stream of its own; begin() / end() take their one snapshot of
+// the table under std::call_once).
 //
 // One difference in WHEN a full table shows: upstream's add() returns false on the very call that cannot
 // be placed (src/mer_database.hpp:97-99). Here a batch of up to 2^20 adds is placed at once, so add()
@@ -115,6 +116,7 @@ public:
       if (pre[i] < '0' || pre[i] > '9') return false;
       hlen = hlen * 10 + (size_t)(pre[i] - '0');
     }
+    if (hlen >= ((size_t)1 << 26)) return false;  // as the library's own reader: no header is that long
     std::string buf(pre, 9);
     buf.resize(9 + hlen);
     if (hlen && !is.read(&buf[9], (std::streamsize)hlen)) return false;
@@ -221,8 +223,12 @@ class database_query {
 public:
   // database_query(const char* filename, bool no_mmap = false) (:270); throws on open/parse failure
   explicit database_query(const char* filename, bool /*no_mmap*/ = false, int device = 0) : q_(0) {
+    // parse_header (:257-267): upstream builds the "Wrong type" error at :264-265 and forgets to throw it; throwing
+    // is what it means to do, and what happens here, before anything of the file is loaded
+    if (!header_.read(filename)) throw std::runtime_error(qh_last_error());
+    if (!header_.check_format())
+      throw std::runtime_error(std::string("Wrong type '") + header_.format() + "' for file '" + filename + "'");
     if (qh_query_open(&q_, filename, device) != QH_OK) throw std::runtime_error(qh_last_error());
-    header_.read(filename);
   }
   ~database_query() { qh_query_close(q_); }
   database_query(const database_query&) = delete;
@@ -297,9 +303,9 @@ public:
 
 private:
   mutable std::vector<value_type> content_;
-  mutable bool loaded_ = false;
-  void load() const {
-    if (loaded_) return;
+  mutable std::once_flag loaded_;
+  void load() const { std::call_once(loaded_, [this]() { load_once(); }); }  // a throw leaves the flag unset
+  void load_once() const {
     uint64_t n = 0;
     if (qh_query_dump(q_, 0, 0, 0, &n) != QH_OK) throw std::runtime_error(qh_last_error());
     std::vector<uint64_t> mers(n), vals(n);
@@ -307,7 +313,6 @@ private:
     content_.reserve(n);
     for (uint64_t i = 0; i < n; ++i)
       content_.push_back(value_type(mer_dna(mers[i]), std::pair<uint64_t, int>(vals[i] >> 1, (int)(vals[i] & 1))));
-    loaded_ = true;
   }
 };
 

@@ -112,15 +112,13 @@ bool qh_make_geom(int k, int bits, uint64_t size, int min_qual, int reprobe_limi
   g.vmask = qh_low_mask(g.vbits);
   g.max_val = ~0ull >> (64 - bits);  // mer_database.hpp:83
   if (g.vbits + g.pbits + g.rbits > 64) {
-    // upstream keeps the values in an array of their own and takes -b up to 63 (create_database.cc:111-112); here key,
-    // probe and value share one 64-bit word: name the largest -b this -m / -s / -p leaves room for
-    const int room = 64 - g.rbits - g.pbits - 1;
-    snprintf(m, sizeof m,
-             "unsupported geometry: %d remainder + %d probe + %d value bits exceed one 64-bit slot: with -m %d, this -s and "
-             "-p %d the largest -b is %d (a larger -s or a smaller -p leaves more)", g.rbits, g.pbits, g.vbits, k,
-             reprobe_limit, room > 0 ? room : 0);
-    err = m;
-    return false;
+    // upstream keeps the values in an array of their own and takes -b up to 63 at any -m / -s
+    // (create_database.cc:111-112, mer_database.hpp:78-83). Where key, probe and value do not share one 64-bit word,
+    // so does this table: the wide form (qh_spec.h), a compatibility route on the direct global-CAS path.
+    if (g.pbits + g.rbits > 64) { err = "unsupported geometry: remainder and probe fields exceed one 64-bit slot"; return false; }
+    g.wide = 1;
+    g.vbits = 0;
+    g.vmask = 0;
   }
   return true;
 }
@@ -160,9 +158,11 @@ extern "C" int qh_build_create(qh_build** out, int k, int bits, uint64_t size, i
   { int src = scratch_resolve(device, &h->noalloc_scratch); if (src) { qh_build_destroy(h); return src; } }
   const size_t bytes = (size_t)8 << g.lsize;
   e = hipMalloc((void**)&h->table, bytes);
+  if (e == hipSuccess && g.wide) e = hipMalloc((void**)&h->g.wvals, bytes);  // the side array of the wide form
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_meta, sizeof(qh_meta));
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_meta, sizeof(qh_meta), hipHostMallocDefault);
   if (e == hipSuccess) e = hipMemsetAsync(h->table, 0, bytes, h->stream);
+  if (e == hipSuccess && g.wide) e = hipMemsetAsync(h->g.wvals, 0, bytes, h->stream);
   if (e == hipSuccess) e = hipMemsetAsync(h->d_meta, 0, sizeof(qh_meta), h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   if (e != hipSuccess) {
@@ -182,7 +182,7 @@ extern "C" void qh_build_destroy(qh_build* h) {
   if (!h) return;
   hipError_t e = hipSetDevice(h->device); (void)e;
   if (h->stream) { e = hipStreamSynchronize(h->stream); (void)e; }
-  void* ptrs[] = {h->table, h->d_meta, h->d_chunk, h->d_recs, h->d_tiles, h->d_ovf[0], h->d_ovf[1], h->d_items, h->d_shard_counts, h->d_rbsums, h->d_segdesc, h->d_planes, h->d_nlplane,
+  void* ptrs[] = {h->table, h->g.wvals, h->d_meta, h->d_chunk, h->d_recs, h->d_tiles, h->d_ovf[0], h->d_ovf[1], h->d_items, h->d_shard_counts, h->d_rbsums, h->d_segdesc, h->d_planes, h->d_nlplane,
                   h->d_bins[0], h->d_bins[1], h->d_bin_counts[0], h->d_bin_counts[1]};
   for (void* p : ptrs) if (p) { e = hipFree(p); (void)e; }
   if (h->h_meta) { e = hipHostFree(h->h_meta); (void)e; }
@@ -206,6 +206,7 @@ static int materialize(qh_build* h) {
   if (!h->zero_pending) return QH_OK;
   QH_HIP(hipSetDevice(h->device));
   QH_HIP(hipMemsetAsync(h->table, 0, (size_t)8 << h->g.lsize, h->stream));
+  if (h->g.wide) QH_HIP(hipMemsetAsync(h->g.wvals, 0, (size_t)8 << h->g.lsize, h->stream));
   h->zero_pending = false;
   return QH_OK;
 }
@@ -224,11 +225,16 @@ static int grow_table(qh_build* h, int target_lsize) {
       return qh_fail(QH_EFULL, "Hash is full");
     const size_t bytes = (size_t)8 << ng.lsize;
     hipError_t e = hipMalloc((void**)&new_table, bytes);
+    if (e == hipSuccess && ng.wide) {  // new_vals_ (mer_database.hpp:148)
+      e = hipMalloc((void**)&ng.wvals, bytes);
+      if (e != hipSuccess) { (void)hipFree(new_table); new_table = nullptr; }
+    }
     if (e != hipSuccess) {  // new_keys_ allocation threw: FULL (mer_database.hpp:149-163)
       (void)hipGetLastError();
       return qh_fail(QH_EFULL, "Hash is full (cannot allocate a %zu-byte table: %s)", bytes, hipGetErrorString(e));
     }
     QH_HIP(hipMemsetAsync(new_table, 0, bytes, h->stream));
+    if (ng.wide) QH_HIP(hipMemsetAsync(ng.wvals, 0, bytes, h->stream));
     QH_HIP(hipMemsetAsync(h->d_meta, 0, sizeof(qh_meta), h->stream));
     qh_launch_rehash(h->table, h->g, new_table, ng, h->d_meta, h->stream);
     QH_HIP(hipGetLastError());
@@ -237,8 +243,10 @@ static int grow_table(qh_build* h, int target_lsize) {
     if (!h->h_meta->rehash_fail) break;
     QH_HIP(hipFree(new_table));  // a key did not fit: try a bigger table
     new_table = nullptr;
+    if (ng.wvals) QH_HIP(hipFree(ng.wvals));
   }
   QH_HIP(hipFree(h->table));
+  if (h->g.wvals) QH_HIP(hipFree(h->g.wvals));
   h->table = new_table;
   h->g = ng;
   h->st.slots = 1ull << ng.lsize;
@@ -366,6 +374,7 @@ static int begin_chunk(qh_build* h, size_t max_items) {
 static bool use_partition(const qh_build* h, size_t max_items) {
   const int wid_bits = h->g.lsize - QH_WINDOW_BITS;
   if (h->g.wbits != QH_WINDOW_BITS || wid_bits < 0 || wid_bits > 24) return false;
+  if (h->g.wide) return false;  // the LDS windows hold whole entries: the wide form stays on the direct path
   if (h->mode == 1) return false;
   if (h->mode == 2) return true;
   return wid_bits >= 8 && max_items >= (((size_t)1 << h->g.lsize) >> 3);
@@ -750,7 +759,7 @@ extern "C" int qh_contaminant_open_fasta(qh_query** out, const char* path, int k
   if (rc) return rc;
   if ((rc = qh_build_add_fasta(b, data.data(), data.size())) || (rc = qh_build_sync(b))) { qh_build_destroy(b); return rc; }
   rc = qh_query_from_table(b->device, b->table, b->g, out);
-  if (rc == QH_OK) { (*out)->owns_table = true; b->table = nullptr; }  // the set outlives its builder
+  if (rc == QH_OK) { (*out)->owns_table = true; b->table = nullptr; b->g.wvals = nullptr; }  // the set outlives its builder
   qh_build_destroy(b);
   return rc;
 }
@@ -990,7 +999,7 @@ extern "C" int qh_build_write_shard(qh_build* h, const char* path, int argc, con
   }
   const uint64_t slots = 1ull << h->g.lsize;
   const uint64_t first = (uint64_t)h->g.shard_id * slots;
-  const int vbits = h->g.vbits;
+  const int vbits = h->g.bits + 1;
   const uint64_t vpw = 64 / vbits;
   const uint64_t w0 = first / vpw, w1 = (first + slots + vpw - 1) / vpw;  // value words touched by this shard
   // values image packed on the GPU while the keys image is on its way out

@@ -105,11 +105,14 @@ __device__ __forceinline__ uint32_t ec_code0(const ec_mer& m) { return (m.a0 & 1
 // WM, the word mode of a kernel: 0 = the value field and the remainder + probe fields (the tag) each fit 32 bits
 // (k = 24 at genome-size tables): counts and tag compares are 32-bit; 1 = 64-bit tags, 32-bit values (k = 31, and
 // every run with a contaminant set, whose small table has long tags): a slot is 64 bits, so a tag of more than 32
-// bits leaves a value of fewer; 2 = everything 64-bit (a value field of more than 32 bits: -b above 31).
+// bits leaves a value of fewer; 2 = everything 64-bit (a value field of more than 32 bits: -b above 31); 3 = like 2,
+// and a table may be in the wide form (qh_spec.h): a slot that matches names the word of the side array that holds
+// the value (the compatibility route for geometries whose key and value do not share one word).
 template <int WM> struct ec_tagw { typedef uint64_t type; };
 template <> struct ec_tagw<0> { typedef uint32_t type; };
 template <int WM> struct ec_valw { typedef uint32_t type; };
 template <> struct ec_valw<2> { typedef uint64_t type; };
+template <> struct ec_valw<3> { typedef uint64_t type; };
 
 // database_query::operator[] for N hashed mers at once. Probing is linear inside a 2^wbits-slot
 // window, so consecutive probes are consecutive words: every round loads the 64-byte line of eight
@@ -156,7 +159,10 @@ __device__ __forceinline__ void ec_lookup_wide(const qh_geom& g, const uint64_t*
         const uint64_t sj = grp[n].s[j];
         if (pend[n] && idx >= 0) {
           if (idx > g.max_reprobe || sj == 0) pend[n] = false;
-          else if ((W)(sj >> g.vbits) == (tag0[n] | (W)(idx + 1))) { v[n] = (V)sj & (V)g.vmask; pend[n] = false; }
+          else if ((W)(sj >> g.vbits) == (tag0[n] | (W)(idx + 1))) {
+            v[n] = (WM == 3 && g.wide) ? (V)g.wvals[gaddr[n] + (uint64_t)j] : (V)sj & (V)g.vmask;
+            pend[n] = false;
+          }
         }
       }
       if (pend[n]) {  // next group of the window (wraps at the window's end)
@@ -179,9 +185,10 @@ __device__ __forceinline__ uint64_t ec_lookup_narrow_table(const qh_geom& g, con
   const uint64_t wmask = qh_low_mask(g.wbits);
   const uint64_t base = p.home & ~wmask;
   for (uint32_t i = 0; i <= (uint32_t)g.max_reprobe; ++i) {
-    const uint64_t s = table[base | ((p.home + i) & wmask)];
+    const uint64_t at = base | ((p.home + i) & wmask);
+    const uint64_t s = table[at];
     if (s == 0) return 0;
-    if ((s >> g.vbits) == (p.tag0 | (i + 1))) return s & g.vmask;
+    if ((s >> g.vbits) == (p.tag0 | (i + 1))) return qh_slot_val(g, s, at);
   }
   return 0;
 }
@@ -254,7 +261,8 @@ __device__ __forceinline__ void ec_lookup_siblings(const qh_geom& g, const uint6
       const bool valid = (uint32_t)(pi + j) <= span;
       stop |= valid && sj == 0;
       const W t = valid ? (W)(sj >> g.vbits) - (W)(pi + j + 1) : (W)1;
-      const V val = (V)sj & (V)g.vmask;
+      // (wide form: the slot's index + 1 stands in for its value until the walk is over)
+      const V val = (WM == 3 && g.wide) ? (V)(gaddr + (uint64_t)j + 1u) : (V)sj & (V)g.vmask;
 #pragma unroll
       for (int y = 0; y < 4; ++y) w[y] = t == tag[y] ? val : w[y];
     }
@@ -262,6 +270,10 @@ __device__ __forceinline__ void ec_lookup_siblings(const qh_geom& g, const uint6
     if (stop || (w[0] != 0 && w[1] != 0 && w[2] != 0 && w[3] != 0)) break;
     gaddr = (gaddr & ~(uint64_t)wmask) | (((uint32_t)gaddr + (uint32_t)EC_GROUP) & wmask);
     pi += EC_GROUP;
+  }
+  if (WM == 3 && g.wide) {
+#pragma unroll
+    for (int y = 0; y < 4; ++y) w[y] = w[y] ? (V)g.wvals[(uint64_t)w[y] - 1u] : (V)0;
   }
 }
 
@@ -358,7 +370,10 @@ void qh_launch_best_alternatives(const uint64_t* table, const qh_geom& g, const 
   }
   uint64_t blocks = (n + 255) / 256;
   if (blocks > 16384) blocks = 16384;
-  if (g.vbits <= 32 && g.rbits + g.pbits <= 32)
+  if (g.wide)
+    hipLaunchKernelGGL(k_best_alternatives_sib<3>, dim3((unsigned)blocks), dim3(256), 0, s, table, g, fmers, backward, n,
+                       counts, ucode, level, nkept);
+  else if (g.vbits <= 32 && g.rbits + g.pbits <= 32)
     hipLaunchKernelGGL(k_best_alternatives_sib<0>, dim3((unsigned)blocks), dim3(256), 0, s, table, g, fmers, backward, n,
                        counts, ucode, level, nkept);
   else if (g.vbits <= 32)
@@ -1201,7 +1216,7 @@ static int corrector_init(qh_corrector* c) {
     const char* ev = getenv("QH_EC_TABLE_LOAD");
     const double target = ev ? atof(ev) : 0.3;
     const qh_geom og = c->P.g;
-    if (target > 0 && og.shard_bits == 0) {
+    if (target > 0 && og.shard_bits == 0 && !og.wide) {
       QH_HIP(hipMemsetAsync(c->d_meta, 0, sizeof(qh_meta), c->stream));
       qh_launch_stats(c->P.table, og, c->d_meta, c->stream);
       QH_HIP(hipMemcpyAsync(c->h_meta, c->d_meta, sizeof(qh_meta), hipMemcpyDeviceToHost, c->stream));
@@ -1254,7 +1269,7 @@ static int corrector_init(qh_corrector* c) {
   const qh_geom& cg = c->P.cg;
   const bool val32 = g.vbits <= 32 && (!c->P.ctable || cg.vbits <= 32);
   const bool tag32 = g.rbits + g.pbits <= 32 && (!c->P.ctable || cg.rbits + cg.pbits <= 32);
-  c->word_mode = val32 ? (tag32 ? 0 : 1) : 2;
+  c->word_mode = (g.wide || (c->P.ctable && cg.wide)) ? 3 : val32 ? (tag32 ? 0 : 1) : 2;
   c->siblings = g.k >= 4 && g.wbits >= 3 && g.lsize + g.shard_bits <= 2 * (g.k - 2);
   QH_HIP(hipMalloc((void**)&c->d_P, sizeof(qh_ec_dev)));
   QH_HIP(hipMemcpy(c->d_P, &c->P, sizeof(qh_ec_dev), hipMemcpyHostToDevice));
@@ -1330,7 +1345,9 @@ static int enqueue_correct(qh_corrector* c, const uint8_t* dev_buf, size_t len, 
     case 2: launch(k_correct_reads<1, false>); break;
     case 3: launch(k_correct_reads<1, true>); break;
     case 4: launch(k_correct_reads<2, false>); break;
-    default: launch(k_correct_reads<2, true>); break;
+    case 5: launch(k_correct_reads<2, true>); break;
+    case 6: launch(k_correct_reads<3, false>); break;
+    default: launch(k_correct_reads<3, true>); break;
   }
   QH_HIP(hipEventRecord(c->ev[2], c->stream));
   hipLaunchKernelGGL(k_ec_block_sums, dim3(nblocks ? nblocks : 1), dim3(EC_FMT_BLOCK), 0, c->stream, c->d_res, c->d_meta,

@@ -307,8 +307,8 @@ void qh_header_from_geom(const qh_geom& g, qh_file_header& h) {
   h.max_reprobe = g.max_reprobe;
   h.bits = g.bits;
   h.key_bytes = h.size * 8;
-  h.value_bytes = qh_vals_bytes(h.size, g.vbits);
-  h.layout = "slot64/1";
+  h.value_bytes = qh_vals_bytes(h.size, g.bits + 1);
+  h.layout = g.wide ? QH_LAYOUT_WIDE : "slot64/1";
   h.hash = "feistel3-core/2";
   h.window_bits = g.wbits;
   h.probe_bits = g.pbits;
@@ -317,7 +317,7 @@ void qh_header_from_geom(const qh_geom& g, qh_file_header& h) {
 
 bool qh_geom_from_header(const qh_file_header& h, qh_geom& g, std::string& err) {
   if (h.format != "binary/quorum_db") { err = "Wrong type '" + h.format + "'"; return false; }  // mer_database.hpp:264-265
-  if (h.layout != "slot64/1" || h.hash != "feistel3-core/2") {
+  if ((h.layout != "slot64/1" && h.layout != QH_LAYOUT_WIDE) || h.hash != "feistel3-core/2") {
     err = "keys image layout '" + h.layout + "'/hash '" + h.hash + "' is not the native slot64/1 + feistel3-core/2 (upstream Jellyfish images are not readable)";
     return false;
   }
@@ -330,7 +330,8 @@ bool qh_geom_from_header(const qh_file_header& h, qh_geom& g, std::string& err) 
   if (qh_table_slots(g) != h.size) { err = "size below the minimum table size"; return false; }
   if ((uint32_t)g.pbits != h.probe_bits) { err = "probe_bits mismatch"; return false; }
   if (h.key_bytes != h.size * 8) { err = "key_bytes does not match size"; return false; }
-  if (h.value_bytes != qh_vals_bytes(h.size, g.vbits)) { err = "value_bytes does not match size/bits"; return false; }
+  if (h.value_bytes != qh_vals_bytes(h.size, g.bits + 1)) { err = "value_bytes does not match size/bits"; return false; }
+  if ((h.layout == QH_LAYOUT_WIDE) != (g.wide != 0)) { err = "keys image layout '" + h.layout + "' does not match the geometry"; return false; }
   return true;
 }
 

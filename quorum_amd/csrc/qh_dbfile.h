@@ -28,6 +28,9 @@
 #include "qh_spec.h"
 
 #define QH_LAYOUT_JF "jellyfish/large_hash"   // internal name; never written to a file
+// keys image of the wide form (qh_spec.h): slots hold [remainder | probe+1] only, every value lives in the vals image
+// (large -b, or long mers in small tables: what would not fit one 64-bit word together)
+#define QH_LAYOUT_WIDE "slot64-keys/1"
 
 struct qh_file_header {
   std::string format;        // "binary/quorum_db"
@@ -39,7 +42,7 @@ struct qh_file_header {
   uint64_t key_bytes = 0, value_bytes = 0;
   uint64_t offset = 0;       // start of the keys image
   // native layout parameters ("qhip" object)
-  std::string layout;        // "slot64/1"
+  std::string layout;        // "slot64/1", or QH_LAYOUT_WIDE
   uint32_t window_bits = 0, probe_bits = 0, shard_bits = 0;
   std::string hash;          // "feistel3-core/2"
   // layout "jellyfish/large_hash" (qh_jflayout.h; no "qhip" object in the JSON): the matrix1 object and reprobes[]

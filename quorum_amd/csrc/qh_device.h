@@ -219,8 +219,38 @@ __device__ __forceinline__ void qh_stage_text_planes_flags(const uint32_t (&f)[4
 
 // hash_with_quality::add on the single-word slot table. Returns false when the
 // reprobe limit is exhausted (caller queues the item for after the doubling).
+// Wide form (qh_spec.h): the slot holds the key only and is claimed first; the value is then updated in the side
+// array by the compare-and-swap loop of mer_database.hpp:102-111 itself -- two dependent random accesses, as upstream.
+__device__ __noinline__ bool qh_insert_wide(const qh_geom& g, uint64_t* __restrict__ table, uint64_t home,
+                                            uint64_t tag0, uint32_t q, uint32_t* is_new) {
+  const uint64_t wmask = qh_low_mask(g.wbits);
+  const uint64_t base = home & ~wmask;
+  for (uint32_t i = 0; i <= (uint32_t)g.max_reprobe; ++i) {
+    const uint64_t idx = base | ((home + i) & wmask);
+    unsigned long long* slot = reinterpret_cast<unsigned long long*>(table + idx);
+    const uint64_t want = tag0 | (i + 1);
+    uint64_t old = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == 0) {
+      old = atomicCAS(slot, 0ull, (unsigned long long)want);
+      if (old == 0) { *is_new = 1; old = want; }
+    }
+    if (old != want) continue;  // another key lives here: next probe
+    unsigned long long* vp = reinterpret_cast<unsigned long long*>(g.wvals + idx);
+    uint64_t v = __hip_atomic_load(vp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+      uint64_t nv;
+      if (!qh_update_val(v, q, g.max_val, &nv)) return true;
+      const uint64_t prev = atomicCAS(vp, (unsigned long long)v, (unsigned long long)nv);
+      if (prev == v) return true;
+      v = prev;
+    }
+  }
+  return false;
+}
+
 __device__ __forceinline__ bool qh_insert(const qh_geom& g, uint64_t* __restrict__ table, uint64_t home,
                                           uint64_t tag0, uint32_t q, uint32_t* is_new) {
+  if (g.wide) return qh_insert_wide(g, table, home, tag0, q, is_new);
   const uint64_t wmask = qh_low_mask(g.wbits);
   const uint64_t base = home & ~wmask;
   const uint64_t fresh = q ? 3u : 2u;  // nval of a new entry (mer_database.hpp:105-110 from 0)

@@ -124,6 +124,9 @@ void qh_launch_dump(const uint64_t* table, const qh_geom& g, uint64_t* mers, uin
 void qh_launch_vals_image(const uint64_t* table, const qh_geom& g, uint64_t first, uint64_t slots, uint64_t w0,
                           uint64_t nwords, uint64_t* out, hipStream_t s);
 
+// wide form: the value fields of a file's values image (bits+1 wide, atomic_bits_array layout) -> side array
+void qh_launch_vals_unpack(const uint64_t* image, int value_bits, uint64_t slots, uint64_t* wvals, hipStream_t s);
+
 // --- roofline microbenchmarks -------------------------------------------------------
 void qh_launch_random_access(uint64_t* table, int lsize, uint64_t n, int mode, uint64_t seed,
                              unsigned long long* sink, hipStream_t s);

@@ -329,14 +329,17 @@ __global__ __launch_bounds__(QH_BLOCK) void k_rehash(const uint64_t* __restrict_
   for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t s = old_table[idx];
     if (!s) continue;
-    const uint64_t val = s & og.vmask;
+    const uint64_t val = qh_slot_val(og, s, idx);
     const qh_pos p = qh_locate_hash(ng, qh_slot_hash(og, s, idx));
     const uint64_t base = p.home & ~wmask;
     bool done = false;
     for (uint32_t i = 0; i <= (uint32_t)ng.max_reprobe && !done; ++i) {
-      unsigned long long* slot = reinterpret_cast<unsigned long long*>(new_table + (base | ((p.home + i) & wmask)));
-      const uint64_t nw = ((p.tag0 | (i + 1)) << ng.vbits) | val;
+      const uint64_t nidx = base | ((p.home + i) & wmask);
+      unsigned long long* slot = reinterpret_cast<unsigned long long*>(new_table + nidx);
+      // (a doubled table has one remainder bit fewer: a wide table may grow into the one-word form)
+      const uint64_t nw = ((p.tag0 | (i + 1)) << ng.vbits) | (ng.wide ? 0ull : val);
       done = atomicCAS(slot, 0ull, (unsigned long long)nw) == 0;  // keys of the old table are distinct
+      if (done && ng.wide) ng.wvals[nidx] = val;
     }
     if (!done) meta->rehash_fail = 1;
   }
@@ -356,12 +359,14 @@ __global__ __launch_bounds__(QH_BLOCK) void k_insert_valued(const uint64_t* __re
   const uint64_t wmask = qh_low_mask(g.wbits);
   for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (uint64_t)gridDim.x * blockDim.x) {
     const qh_pos p = qh_locate(g, mers[idx] & g.kmask);
-    const uint64_t val = vals[idx] & g.vmask;
+    const uint64_t val = vals[idx] & qh_low_mask(g.bits + 1);
     const uint64_t base = p.home & ~wmask;
     bool done = false;
     for (uint32_t i = 0; i <= (uint32_t)g.max_reprobe && !done; ++i) {
-      unsigned long long* slot = reinterpret_cast<unsigned long long*>(table + (base | ((p.home + i) & wmask)));
-      done = atomicCAS(slot, 0ull, (unsigned long long)(((p.tag0 | (i + 1)) << g.vbits) | val)) == 0;
+      const uint64_t nidx = base | ((p.home + i) & wmask);
+      unsigned long long* slot = reinterpret_cast<unsigned long long*>(table + nidx);
+      done = atomicCAS(slot, 0ull, (unsigned long long)(((p.tag0 | (i + 1)) << g.vbits) | (g.wide ? 0ull : val))) == 0;
+      if (done && g.wide) g.wvals[nidx] = val;
     }
     if (!done) meta->rehash_fail = 1;
   }
@@ -396,7 +401,7 @@ __device__ __forceinline__ uint64_t qh_lookup(const qh_geom& g, const uint64_t* 
         const uint64_t sj = L.s[j];
         if (pend && idx >= 0) {
           if (idx > g.max_reprobe || sj == 0) pend = false;
-          else if ((sj >> g.vbits) == (p.tag0 | (uint64_t)(idx + 1))) { v = sj & g.vmask; pend = false; }
+          else if ((sj >> g.vbits) == (p.tag0 | (uint64_t)(idx + 1))) { v = qh_slot_val(g, sj, gaddr + j); pend = false; }
         }
       }
       gaddr = (gaddr & ~(uint64_t)wm) | (((uint32_t)gaddr + 8u) & wm);  // wraps at the window's end
@@ -407,9 +412,10 @@ __device__ __forceinline__ uint64_t qh_lookup(const qh_geom& g, const uint64_t* 
   const uint64_t wmask = qh_low_mask(g.wbits);
   const uint64_t base = p.home & ~wmask;
   for (uint32_t i = 0; i <= (uint32_t)g.max_reprobe; ++i) {
-    const uint64_t s = table[base | ((p.home + i) & wmask)];
+    const uint64_t at = base | ((p.home + i) & wmask);
+    const uint64_t s = table[at];
     if (s == 0) return 0;
-    if ((s >> g.vbits) == (p.tag0 | (i + 1))) return s & g.vmask;
+    if ((s >> g.vbits) == (p.tag0 | (i + 1))) return qh_slot_val(g, s, at);
   }
   return 0;
 }
@@ -516,7 +522,8 @@ __global__ __launch_bounds__(QH_BLOCK) void k_stats(const uint64_t* __restrict__
   const uint64_t n = qh_table_slots(g);
   unsigned long long d = 0, t = 0;
   for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t v = table[idx] & g.vmask;
+    const uint64_t s = table[idx];
+    const uint64_t v = s ? qh_slot_val(g, s, idx) : 0;
     if ((v & 1) && v >= 2) { d += 1; t += v >> 1; }
   }
 #pragma unroll
@@ -541,7 +548,7 @@ __global__ __launch_bounds__(QH_BLOCK) void k_histo(const uint64_t* __restrict__
   for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t s = table[idx];
     if (!s) continue;
-    const uint64_t v = s & g.vmask;
+    const uint64_t v = qh_slot_val(g, s, idx);
     uint64_t c = v >> 1;
     if (c > 1000) c = 1000;
     atomicAdd(&h[c * 2 + (v & 1)], 1u);
@@ -576,7 +583,7 @@ __global__ __launch_bounds__(QH_BLOCK) void k_dump(const uint64_t* __restrict__ 
     base = __shfl(base, leader, 64);
     if (s) {
       const unsigned long long at = base + lanes_below(mask);
-      if (at < cap) { mers[at] = qh_slot_key(g, s, idx); vals[at] = s & g.vmask; }
+      if (at < cap) { mers[at] = qh_slot_key(g, s, idx); vals[at] = qh_slot_val(g, s, idx); }
     }
   }
 }
@@ -601,16 +608,33 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 __global__ __launch_bounds__(QH_BLOCK) void k_vals_image(const uint64_t* __restrict__ table, const qh_geom g,
                                                          uint64_t first, uint64_t slots, uint64_t w0, uint64_t nwords,
                                                          uint64_t* __restrict__ out) {
-  const uint32_t vpw = 64u / (uint32_t)g.vbits;
+  const uint32_t vb = (uint32_t)g.bits + 1u, vpw = 64u / vb;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t base = (w0 + i) * vpw;
     uint64_t word = 0;
     for (uint32_t j = 0; j < vpw; ++j) {
       const uint64_t gi = base + j;
-      if (gi >= first && gi - first < slots) word |= (table[gi - first] & g.vmask) << (j * g.vbits);
+      if (gi >= first && gi - first < slots) {
+        const uint64_t s = table[gi - first];
+        if (s) word |= qh_slot_val(g, s, gi - first) << (j * vb);
+      }
     }
     out[i] = word;
   }
+}
+
+// the reverse for a table in the wide form read from a file: value fields of the image -> side array
+__global__ __launch_bounds__(QH_BLOCK) void k_vals_unpack(const uint64_t* __restrict__ image, int vb, uint64_t slots,
+                                                          uint64_t* __restrict__ wvals) {
+  const uint32_t vpw = 64u / (uint32_t)vb;
+  const uint64_t vm = qh_low_mask(vb);
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (uint64_t)gridDim.x * blockDim.x)
+    wvals[i] = (image[i / vpw] >> ((i % vpw) * (uint32_t)vb)) & vm;
+}
+
+void qh_launch_vals_unpack(const uint64_t* image, int value_bits, uint64_t slots, uint64_t* wvals, hipStream_t s) {
+  if (!slots) return;
+  hipLaunchKernelGGL(k_vals_unpack, dim3(grid_for(slots, QH_BLOCK, 16384)), dim3(QH_BLOCK), 0, s, image, value_bits, slots, wvals);
 }
 
 void qh_launch_vals_image(const uint64_t* table, const qh_geom& g, uint64_t first, uint64_t slots, uint64_t w0,

@@ -123,8 +123,7 @@ extern "C" int qh_query_open(qh_query** out, const char* path, int device) {
     close(fd); qh_query_close(q);
     return qh_fail(QH_ENOMEM, "cannot allocate the staging buffers");
   }
-  const uint64_t image_off = fh.offset;
-  auto read_piece = [&](char* dst, size_t n, uint64_t at) -> bool {
+  auto read_piece = [&](char* dst, size_t n, uint64_t file_at) -> bool {
     unsigned nt = std::thread::hardware_concurrency();
     if (nt > 8) nt = 8;
     if (nt < 1 || n < ((size_t)16 << 20)) nt = 1;
@@ -137,7 +136,7 @@ extern "C" int qh_query_open(qh_query** out, const char* path, int device) {
       th.emplace_back([=, &bad]() {
         size_t got = from;
         while (got < to) {
-          ssize_t r = pread(fd, dst + got, to - got, (off_t)(image_off + at + got));
+          ssize_t r = pread(fd, dst + got, to - got, (off_t)(file_at + got));
           if (r < 0 && errno == EINTR) continue;
           if (r <= 0) { bad[t] = 1; return; }
           got += (size_t)r;
@@ -151,21 +150,46 @@ extern "C" int qh_query_open(qh_query** out, const char* path, int device) {
   rc = QH_OK;
   bool used[2] = {false, false};
   int b = 0;
-  for (uint64_t at = 0; at < fh.key_bytes && rc == QH_OK; at += piece, b ^= 1) {
-    const size_t n = fh.key_bytes - at < piece ? (size_t)(fh.key_bytes - at) : piece;
-    if (used[b]) {  // the copy that last read this piece must be done before the file overwrites it
-      e = hipEventSynchronize(ev[b]);
-      if (e != hipSuccess) { rc = qh_fail(QH_EHIP, "copying the table to the device failed: %s", hipGetErrorString(e)); break; }
+  // `bytes` of the file from `file_off` on -> device memory at dst
+  auto stream_in = [&](char* dst, uint64_t file_off, uint64_t bytes) {
+    for (uint64_t at = 0; at < bytes && rc == QH_OK; at += piece, b ^= 1) {
+      const size_t n = bytes - at < piece ? (size_t)(bytes - at) : piece;
+      if (used[b]) {  // the copy that last read this piece must be done before the file overwrites it
+        e = hipEventSynchronize(ev[b]);
+        if (e != hipSuccess) { rc = qh_fail(QH_EHIP, "copying the table to the device failed: %s", hipGetErrorString(e)); break; }
+      }
+      if (!read_piece((char*)stage[b], n, file_off + at)) { rc = qh_fail(QH_EIO, "Failed to read in file '%s'", path); break; }
+      e = hipMemcpyAsync(dst + at, stage[b], n, hipMemcpyHostToDevice, q->stream);
+      if (e == hipSuccess) e = hipEventRecord(ev[b], q->stream);
+      used[b] = true;
+      if (e != hipSuccess) rc = qh_fail(QH_EHIP, "copying the table to the device failed: %s", hipGetErrorString(e));
     }
-    if (!read_piece((char*)stage[b], n, at)) { rc = qh_fail(QH_EIO, "Failed to read in file '%s'", path); break; }
-    e = hipMemcpyAsync((char*)q->table + at, stage[b], n, hipMemcpyHostToDevice, q->stream);
-    if (e == hipSuccess) e = hipEventRecord(ev[b], q->stream);
-    used[b] = true;
-    if (e != hipSuccess) rc = qh_fail(QH_EHIP, "copying the table to the device failed: %s", hipGetErrorString(e));
+  };
+  stream_in((char*)q->table, fh.offset, fh.key_bytes);
+  uint64_t* d_vimg = nullptr;
+  if (rc == QH_OK && g.wide) {
+    // wide form: the slots hold keys only; the values image (atomic_bits_array layout) supplies the side array
+    const int vb = g.bits + 1;
+    e = hipMalloc((void**)&q->g.wvals, fh.key_bytes);
+    if (e == hipSuccess && vb <= 32) e = hipMalloc((void**)&d_vimg, fh.value_bytes);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      rc = qh_fail(QH_ENOMEM, "cannot allocate %llu bytes of HBM for the values: %s", (unsigned long long)fh.key_bytes, hipGetErrorString(e));
+    } else if (vb > 32) {
+      stream_in((char*)q->g.wvals, fh.offset + fh.key_bytes, fh.value_bytes);  // one field per word: the image is the array
+    } else {
+      stream_in((char*)d_vimg, fh.offset + fh.key_bytes, fh.value_bytes);
+      if (rc == QH_OK) {
+        qh_launch_vals_unpack(d_vimg, vb, fh.size, q->g.wvals, q->stream);
+        e = hipGetLastError();
+        if (e != hipSuccess) rc = qh_fail(QH_EHIP, "unpacking the values image failed: %s", hipGetErrorString(e));
+      }
+    }
   }
   e = hipStreamSynchronize(q->stream);
   if (e != hipSuccess && rc == QH_OK) rc = qh_fail(QH_EHIP, "copying the table to the device failed: %s", hipGetErrorString(e));
   for (int i = 0; i < 2; ++i) { (void)hipHostFree(stage[i]); (void)hipEventDestroy(ev[i]); }
+  if (d_vimg) (void)hipFree(d_vimg);
   close(fd);
   if (rc) { qh_query_close(q); return rc; }
   *out = q;
@@ -206,7 +230,7 @@ extern "C" void qh_query_close(qh_query* q) {
   if (!q) return;
   hipError_t e = hipSetDevice(q->device); (void)e;
   if (q->stream) { e = hipStreamSynchronize(q->stream); (void)e; }
-  void* ptrs[] = {q->owns_table ? (void*)q->table : nullptr, q->d_meta, q->d_out};
+  void* ptrs[] = {q->owns_table ? (void*)q->table : nullptr, q->owns_table ? (void*)q->g.wvals : nullptr, q->d_meta, q->d_out};
   for (void* p : ptrs) if (p) { e = hipFree(p); (void)e; }
   for (qh_query::lane* l : q->lanes) {
     if (l->stream) { e = hipStreamSynchronize(l->stream); (void)e; }

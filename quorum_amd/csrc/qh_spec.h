@@ -24,6 +24,7 @@
 // probing     = linear inside the 2^wbits-slot window that contains the home
 //               slot: idx = (home & ~wmask) | ((home + i) & wmask), i <= max_reprobe
 // A slot is empty iff the whole word is 0 (an occupied slot has probe+1 >= 1).
+// Wide form (qh_geom::wide): vbits = 0, the slot is [ remainder | probe+1 ] and the value of slot i is wvals[i].
 // The key of an occupied slot is recovered as
 //   qh_unmix( remainder << gsize | ((window base | (idx - i) & wmask)) << shard_bits | shard ).
 // A table that holds ALL shards back to back (all_shards = 1: the serialised file,
@@ -51,7 +52,7 @@
 struct qh_geom {
   int32_t k;            // mer length, 1..31
   int32_t bits;         // count bits (-b); value field is bits+1 wide
-  int32_t vbits;        // bits + 1
+  int32_t vbits;        // width of the value field INSIDE the slot: bits + 1, or 0 in the wide form
   int32_t pbits;        // width of the probe+1 field
   int32_t rbits;        // width of the remainder field
   int32_t lsize;        // log2(slots in THIS shard)
@@ -65,6 +66,13 @@ struct qh_geom {
   uint64_t hmask;       // 2^(2k+1) - 1: the hash of a key is one bit wider than the key
   uint64_t vmask;       // 2^vbits - 1
   uint64_t max_val;     // 2^bits - 1
+  // Wide form (remainder + probe + value fields would exceed 64 bits: large -b, or long mers in small tables): the
+  // slot keeps [remainder | probe+1] only and the bits+1-wide value lives in a side array of one 64-bit word per slot,
+  // like upstream's separate val_array (src/mer_database.hpp:78-83). `wvals` is that array's device address: it rides
+  // in the geometry so that every kernel that is handed a table can reach the values that belong to it.
+  int32_t wide;
+  int32_t reserved_;
+  uint64_t* wvals;
 };
 
 QH_HD uint64_t qh_low_mask(int n) { return n >= 64 ? ~0ULL : ((1ULL << n) - 1); }
@@ -271,6 +279,11 @@ QH_HD uint64_t qh_slot_hash(const qh_geom& g, uint64_t slot, uint64_t idx) {
 // key stored in the occupied slot word `slot` found at index `idx`
 QH_HD uint64_t qh_slot_key(const qh_geom& g, uint64_t slot, uint64_t idx) {
   return qh_key_from_pkey(qh_unmix(qh_slot_hash(g, slot, idx), g.k), g.k);
+}
+
+// value (count << 1 | hq) of the occupied slot word `slot` found at index `idx`
+QH_HD uint64_t qh_slot_val(const qh_geom& g, uint64_t slot, uint64_t idx) {
+  return g.wide ? g.wvals[idx] : slot & g.vmask;
 }
 
 // Quorum's update rule (src/mer_database.hpp:104-110) on a value field.

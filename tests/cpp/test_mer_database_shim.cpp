@@ -165,6 +165,19 @@ int main(int argc, char* argv[]) {
     for (auto& t : th) t.join();
     EXPECT(wrong.load() == 0);
   }
+  {
+    // begin() / end() from two threads at once on a handle nobody has iterated yet: one snapshot, both see all of it
+    std::atomic<size_t> seen[2];
+    seen[0] = 0; seen[1] = 0;
+    auto walk = [&](int t) {
+      size_t c = 0;
+      for (database_query::const_iterator it = database.begin(); it != database.end(); ++it) ++c;
+      seen[t] = c;
+    };
+    std::thread a(walk, 0), b(walk, 1);
+    a.join(); b.join();
+    EXPECT(seen[0].load() == mer_map.size() && seen[1].load() == mer_map.size());
+  }
   size_t n = 0;
   for (database_query::const_iterator it = database.begin(); it != database.end(); ++it, ++n) {  // :123-134
     mer_map_t::const_iterator counts = mer_map.find(it->first.word());
@@ -183,6 +196,25 @@ int main(int argc, char* argv[]) {
   bool threw = false;
   try { database_query missing("/nonexistent/db"); } catch (const std::runtime_error&) { threw = true; }  // :259-260
   EXPECT(threw);
+  {
+    // a file whose header parses but names another format: check_format() is false and database_query refuses it
+    // (what src/mer_database.hpp:264-265 means to do)
+    const std::string other = std::string(path) + ".sorted";
+    const std::string j = "{\"format\":\"binary/sorted\",\"size\":16,\"key_len\":62}";
+    char pre[16];
+    const size_t pad = (8 - (9 + j.size()) % 8) % 8;
+    snprintf(pre, sizeof pre, "%09zu", j.size() + pad);
+    std::ofstream o(other.c_str());
+    o << pre << j << std::string(pad, '\0') << std::string(256, '\0');
+    o.close();
+    database_header oh;
+    EXPECT(oh.read(other.c_str()) && !oh.check_format() && oh.format() == "binary/sorted");
+    bool refused = false;
+    std::string what;
+    try { database_query wrong(other.c_str()); } catch (const std::runtime_error& e) { refused = true; what = e.what(); }
+    EXPECT(refused && what.find("Wrong type 'binary/sorted'") != std::string::npos);
+    unlink(other.c_str());
+  }
   printf("%s: %d failure(s), %zu distinct mers\n", failures ? "FAILED" : "PASSED", failures, n);
   return failures ? 1 : 0;
 }

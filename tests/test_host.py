@@ -41,7 +41,7 @@ def test_version_and_error_string():
 @pytest.mark.parametrize("k,bits,size,msg", [
     (0, 7, 100, "Mer length"), (32, 7, 100, "Mer length"),
     (24, 0, 100, "bits should be between 1 and 63"), (24, 64, 100, "bits should be between 1 and 63"),
-    (24, 7, 0, "size"), (31, 40, 1 << 10, "unsupported geometry")])
+    (24, 7, 0, "size")])
 def test_create_rejects_bad_geometry_without_gpu(k, bits, size, msg):
     h = C.c_void_p()
     st = _lib.lib.qh_build_create(C.byref(h), k, bits, size, 38, 126, 0, 0, 0)
