@@ -61,6 +61,7 @@ typedef struct qh_build_stats {
   uint64_t records;       /* reads consumed                            */
   uint64_t grows;         /* number of 2x table doublings performed    */
   uint64_t foreign;       /* k-mers dropped because another shard owns them */
+  uint64_t window_passes; /* passes over the table by the partitioned build (one per batch of chunks) */
 } qh_build_stats;
 
 const char* qh_last_error(void);
@@ -434,6 +435,17 @@ int qh_build_kernel_time(qh_build* h, int which, double* total_ms, uint64_t* lau
  * level (-1 = automatic). Both strategies produce the same table format and the
  * same content. Also settable with QH_BUILD_MODE=direct|partition, QH_LEVEL1_BITS. */
 int qh_build_set_mode(qh_build* h, int mode, int level1_bits);
+
+/* Deferred window pass of the radix-partitioned build. A partitioned chunk ends in one pass over the whole table
+ * (every probe window is loaded into LDS, its bucket applied, the window streamed back): 16 bytes per SLOT whatever
+ * the chunk's size, which dominates when chunks are small beside the table (a 2^31-slot table: 34 GB per chunk). With
+ * a budget the window buckets of successive chunks accumulate in HBM instead and the table is streamed once per
+ * BATCH: when the budget is used up, and whenever the table must be current -- qh_build_sync, finish, get_stats, dump,
+ * as_query, write, grow_to and the direct-path entry points flush first, so results never depend on the budget.
+ * max_bytes: memory the buckets of a batch may take; 0 = every chunk is flushed at once (the behaviour until round 3),
+ * negative = automatic (three times the table, at most half of the free device memory; the default). Also
+ * QH_DEFER_BYTES. No upstream counterpart (upstream updates its table k-mer by k-mer). */
+int qh_build_set_defer(qh_build* h, long long max_bytes);
 
 /* Random-access roofline microbenchmark: n_updates uniformly random
  * 64-bit atomicCAS (mode 0) or 8-byte loads (mode 1) over a table of 2^lsize

@@ -22,7 +22,7 @@ class QhRecord(C.Structure):
 
 class QhBuildStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
-                ("instances", "hq_instances", "distinct", "slots", "records", "grows", "foreign")]
+                ("instances", "hq_instances", "distinct", "slots", "records", "grows", "foreign", "window_passes")]
 
 
 class QhDbInfo(C.Structure):
@@ -122,6 +122,7 @@ SIGNATURES = [
     ("qh_build_enable_timing", C.c_int, [_p, C.c_int]),
     ("qh_build_kernel_time", C.c_int, [_p, C.c_int, C.POINTER(C.c_double), _u64p]),
     ("qh_build_set_mode", C.c_int, [_p, C.c_int, C.c_int]),
+    ("qh_build_set_defer", C.c_int, [_p, C.c_longlong]),
     ("qh_bench_lds_rate", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("qh_bench_random_access", C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 ]

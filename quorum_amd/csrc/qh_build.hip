@@ -174,6 +174,7 @@ extern "C" int qh_build_create(qh_build** out, int k, int bits, uint64_t size, i
   h->st.slots = 1ull << g.lsize;
   if (const char* m = getenv("QH_BUILD_MODE")) h->mode = !strcmp(m, "direct") ? 1 : !strcmp(m, "partition") ? 2 : 0;
   if (const char* b = getenv("QH_LEVEL1_BITS")) h->level1_bits = atoi(b);
+  if (const char* d = getenv("QH_DEFER_BYTES")) { const long long v = atoll(d); h->defer_budget = v < 0 ? -1 : v; }
   *out = h;
   return QH_OK;
 }
@@ -183,7 +184,7 @@ extern "C" void qh_build_destroy(qh_build* h) {
   hipError_t e = hipSetDevice(h->device); (void)e;
   if (h->stream) { e = hipStreamSynchronize(h->stream); (void)e; }
   void* ptrs[] = {h->table, h->g.wvals, h->d_meta, h->d_chunk, h->d_recs, h->d_tiles, h->d_ovf[0], h->d_ovf[1], h->d_items, h->d_shard_counts, h->d_rbsums, h->d_segdesc, h->d_planes, h->d_nlplane,
-                  h->d_bins[0], h->d_bins[1], h->d_bin_counts[0], h->d_bin_counts[1]};
+                  h->d_bins[0], h->d_bins[1], h->d_bin_counts[0], h->d_bin_counts[1], h->d_wfail[0], h->d_wfail[1], h->d_bspill};
   for (void* p : ptrs) if (p) { e = hipFree(p); (void)e; }
   if (h->h_meta) { e = hipHostFree(h->h_meta); (void)e; }
   for (auto& pr : h->evk) for (hipEvent_t ev : pr) if (ev) { e = hipEventDestroy(ev); (void)e; }
@@ -254,22 +255,37 @@ static int grow_table(qh_build* h, int target_lsize) {
   return QH_OK;
 }
 
-// items that hit the reprobe limit wait in the overflow list; double and retry
-static int grow_and_reinsert(qh_build* h, uint64_t n_ovf) {
-  while (n_ovf) {
+// What a chunk or a window pass could not place: items that hit the reprobe limit on the direct path wait in the
+// overflow list, windows that an item overflowed were left as they were with their buckets intact (k_window_build).
+// The table doubles (handle_full_ary, mer_database.hpp:137-187) and both are run again, until nothing is left.
+static int resolve_full(qh_build* h, uint64_t n_ovf, uint32_t n_winfail) {
+  uint32_t n_prev = h->defer_nw;  // windows of the pass whose flags are in d_wfail[wf]
+  int wf = 0;
+  while (n_ovf || n_winfail) {
     const int src = h->cur_ovf, dst = src ^ 1;
-    int rc = ensure((void**)&h->d_ovf[dst], &h->ovf_cap[dst], n_ovf * 8, "overflow list");
-    if (rc) return rc;
+    int rc;
+    if (n_ovf && (rc = ensure((void**)&h->d_ovf[dst], &h->ovf_cap[dst], n_ovf * 8, "overflow list"))) return rc;
     if ((rc = grow_table(h, h->g.lsize + 1))) return rc;
     QH_HIP(hipMemsetAsync(h->d_meta, 0, sizeof(qh_meta), h->stream));
-    qh_launch_insert_items(h->d_ovf[src], n_ovf, nullptr, 0, 1, h->d_meta, h->g, h->table, h->d_ovf[dst], h->ovf_cap[dst] / 8, h->stream);
+    if (n_ovf)
+      qh_launch_insert_items(h->d_ovf[src], n_ovf, nullptr, 0, 1, h->d_meta, h->g, h->table, h->d_ovf[dst], h->ovf_cap[dst] / 8, h->stream);
+    uint32_t nw = 0;
+    if (n_winfail) {
+      nw = 1u << (h->g.lsize - QH_WINDOW_BITS);
+      if ((rc = ensure((void**)&h->d_wfail[wf ^ 1], &h->wfail_cap[wf ^ 1], (size_t)nw * 4, "window flags"))) return rc;
+      qh_launch_window_redo(h->table, h->g, h->d_bins[1], h->defer_capw, h->d_bin_counts[1], h->defer_nw, nw,
+                            h->d_wfail[wf ^ 1], h->d_wfail[wf], n_prev, h->d_meta, h->stream);
+      h->st.window_passes += 1;
+    }
     QH_HIP(hipGetLastError());
     QH_HIP(hipMemcpyAsync(h->h_meta, h->d_meta, sizeof(qh_meta), hipMemcpyDeviceToHost, h->stream));
     QH_HIP(hipStreamSynchronize(h->stream));
     if (h->h_meta->ovf_lost) return qh_fail(QH_EFULL, "Hash is full (overflow list exhausted)");
     h->st.distinct += h->h_meta->new_keys;
-    h->cur_ovf = dst;
+    if (n_ovf) h->cur_ovf = dst;
     n_ovf = h->h_meta->ovf_count;
+    if (n_winfail) { wf ^= 1; n_prev = nw; }
+    n_winfail = h->h_meta->win_failed;
   }
   return QH_OK;
 }
@@ -283,42 +299,75 @@ extern "C" int qh_build_grow_to(qh_build* h, int lsize) {
   return grow_table(h, lsize);
 }
 
-extern "C" int qh_build_sync(qh_build* h) {
+static int launch_flush(qh_build* h, bool same_epoch);
+
+// Collects the chunk in flight (counters, deferred errors, growth). flush: the public meaning of qh_build_sync --
+// everything fed so far is in the table; without it a batch of deferred chunks stays open (begin_chunk).
+static int sync_impl(qh_build* h, bool flush) {
   if (!h) return qh_fail(QH_EBADARG, "null handle");
   if (h->failed) return qh_fail(h->failed, "%s", h->failed_msg.c_str());
-  if (!h->pending) return QH_OK;
-  QH_HIP(hipSetDevice(h->device));
-  QH_HIP(hipMemcpyAsync(h->h_meta, h->d_meta, sizeof(qh_meta), hipMemcpyDeviceToHost, h->stream));
-  QH_HIP(hipStreamSynchronize(h->stream));
-  h->pending = false;
-  for (int i = 0; i < 4; ++i) {
-    if (!h->evk_pending[i]) continue;
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, h->evk[i][0], h->evk[i][1]) == hipSuccess) { h->kernel_ms[i] += ms; h->kernel_launches[i] += 1; }
-    h->evk_pending[i] = false;
+  for (;;) {
+    if (flush && h->defer_open) { int frc = launch_flush(h, false); if (frc) return frc; }
+    if (!h->pending) return QH_OK;
+    QH_HIP(hipSetDevice(h->device));
+    QH_HIP(hipMemcpyAsync(h->h_meta, h->d_meta, sizeof(qh_meta), hipMemcpyDeviceToHost, h->stream));
+    QH_HIP(hipStreamSynchronize(h->stream));
+    h->pending = false;
+    for (int i = 0; i < 4; ++i) {
+      if (!h->evk_pending[i]) continue;
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, h->evk[i][0], h->evk[i][1]) == hipSuccess) { h->kernel_ms[i] += ms; h->kernel_launches[i] += 1; }
+      h->evk_pending[i] = false;
+    }
+    const qh_meta m = *h->h_meta;
+    const bool was_deferred = h->pending_deferred;
+    const size_t flen = h->pending_fastq_len;
+    h->pending_deferred = false;
+    h->pending_fastq_len = 0;
+    if (m.format_err) {
+      const char* why = (m.format_err & QH_FMT_LINES_MOD4)     ? "line count is not a multiple of 4"
+                        : (m.format_err & QH_FMT_TOO_MANY)     ? "records shorter than the fast path supports"
+                        : (m.format_err & QH_FMT_NO_AT)        ? "a record does not start with '@'"
+                        : (m.format_err & QH_FMT_NO_PLUS)      ? "a separator line does not start with '+'"
+                        : (m.format_err & QH_FMT_LEN_MISMATCH) ? "sequence and quality lengths differ"
+                        : (m.format_err & QH_FMT_LINE_TOO_LONG) ? "a line of 256 MiB or more"
+                                                               : "empty sequence";
+      return qh_fail(QH_EFORMAT, "chunk is not strict 4-line FASTQ (%s, near record %u); nothing was inserted", why, m.first_bad);
+    }
+    h->st.instances += m.instances;
+    h->st.hq_instances += m.hq_instances;
+    h->st.distinct += m.new_keys;
+    h->st.foreign += m.foreign;
+    h->st.records += m.nrec;
+    if (flen && m.instances) {
+      const double r = (double)m.instances / (double)flen;
+      if (r > h->items_per_byte) h->items_per_byte = r;
+    }
+    if (was_deferred) h->defer_items += m.instances;
+    int rc = QH_OK;
+    if (m.ovf_lost) rc = qh_fail(QH_EFULL, "Hash is full (overflow list exhausted)");
+    else if (h->defer_open && m.spill_count) {
+      // items of the last chunk that found their bucket full (windows differ by a few per cent in what they receive)
+      // wait in the spill list, which the next chunk reuses: they move to the batch's own list; when that is full
+      // the batch is applied now (the device-side spill count is kept, the counters just collected are not
+      // counted twice)
+      if ((h->bspill_n + m.spill_count) * 8 <= h->bspill_cap) {
+        QH_HIP(hipMemcpyAsync(h->d_bspill + h->bspill_n, h->defer_spill, m.spill_count * 8, hipMemcpyDeviceToDevice, h->stream));
+        QH_HIP(hipMemsetAsync(&h->d_meta->spill_count, 0, 8, h->stream));
+        h->bspill_n += m.spill_count;
+      } else if ((rc = launch_flush(h, false)) == QH_OK) {
+        continue;
+      }
+    } else if (m.ovf_count || m.win_failed) {
+      if (h->defer_open) rc = qh_fail(QH_EHIP, "internal: overflow items while a deferred batch is open");
+      else rc = resolve_full(h, m.ovf_count, m.win_failed);
+    }
+    if (rc) { h->failed = rc; h->failed_msg = g_last_error; }
+    return rc;
   }
-  const qh_meta m = *h->h_meta;
-  if (m.format_err) {
-    const char* why = (m.format_err & QH_FMT_LINES_MOD4)     ? "line count is not a multiple of 4"
-                      : (m.format_err & QH_FMT_TOO_MANY)     ? "records shorter than the fast path supports"
-                      : (m.format_err & QH_FMT_NO_AT)        ? "a record does not start with '@'"
-                      : (m.format_err & QH_FMT_NO_PLUS)      ? "a separator line does not start with '+'"
-                      : (m.format_err & QH_FMT_LEN_MISMATCH) ? "sequence and quality lengths differ"
-                      : (m.format_err & QH_FMT_LINE_TOO_LONG) ? "a line of 256 MiB or more"
-                                                             : "empty sequence";
-    return qh_fail(QH_EFORMAT, "chunk is not strict 4-line FASTQ (%s, near record %u); nothing was inserted", why, m.first_bad);
-  }
-  h->st.instances += m.instances;
-  h->st.hq_instances += m.hq_instances;
-  h->st.distinct += m.new_keys;
-  h->st.foreign += m.foreign;
-  h->st.records += m.nrec;
-  int rc = QH_OK;
-  if (m.ovf_lost) rc = qh_fail(QH_EFULL, "Hash is full (overflow list exhausted)");
-  else if (m.ovf_count) rc = grow_and_reinsert(h, m.ovf_count);
-  if (rc) { h->failed = rc; h->failed_msg = g_last_error; }
-  return rc;
 }
+
+extern "C" int qh_build_sync(qh_build* h) { return sync_impl(h, true); }
 
 // HIP events around the main kernels of a chunk, on the stream they are launched on
 // (which: 0 direct build / item insert, 1 partition level 1 incl. extraction,
@@ -356,10 +405,38 @@ extern "C" int qh_build_set_mode(qh_build* h, int mode, int level1_bits) {
   return QH_OK;
 }
 
-static int begin_chunk(qh_build* h, size_t max_items) {
-  int rc = qh_build_sync(h);
+static bool use_partition(const qh_build* h, size_t max_items);
+
+// upper estimate of the items a FASTQ chunk of `len` bytes brings: len / 2 (a base and a quality per item at least),
+// or what chunks before it brought per byte, with a margin
+static size_t est_fastq_items(const qh_build* h, size_t len) {
+  const size_t ub = len / 2;
+  if (h->items_per_byte <= 0) return ub;
+  const size_t e = (size_t)((double)len * h->items_per_byte * 1.05) + 4096;
+  return e < ub ? e : ub;
+}
+
+// Before a chunk is enqueued: the chunk in flight is collected; an open batch of deferred chunks is flushed when this
+// chunk does not go into it (direct path) or does not fit it any more.
+extern "C" int qh_build_set_defer(qh_build* h, long long max_bytes) {
+  if (!h) return qh_fail(QH_EBADARG, "null handle");
+  int rc = qh_build_sync(h);  // an open batch was sized under the old budget
+  if (rc) return rc;
+  h->defer_budget = max_bytes < 0 ? -1 : max_bytes;
+  return QH_OK;
+}
+
+static int begin_chunk(qh_build* h, size_t max_items, size_t est_items) {
+  int rc = sync_impl(h, false);
   if (rc) return rc;
   QH_HIP(hipSetDevice(h->device));
+  if (h->defer_open) {
+    const uint32_t nw_now = h->g.lsize >= QH_WINDOW_BITS ? 1u << (h->g.lsize - QH_WINDOW_BITS) : 0;
+    if (!use_partition(h, max_items) || nw_now != h->defer_nw || h->defer_items + est_items > h->defer_cap_items) {
+      if ((rc = launch_flush(h, false))) return rc;
+      if ((rc = sync_impl(h, false))) return rc;
+    }
+  }
   rc = ensure((void**)&h->d_ovf[h->cur_ovf], &h->ovf_cap[h->cur_ovf], (max_items + 1) * 8, "overflow list");
   if (rc) return rc;
   QH_HIP(hipMemsetAsync(h->d_meta, 0, sizeof(qh_meta), h->stream));
@@ -377,7 +454,12 @@ static bool use_partition(const qh_build* h, size_t max_items) {
   if (h->g.wide) return false;  // the LDS windows hold whole entries: the wide form stays on the direct path
   if (h->mode == 1) return false;
   if (h->mode == 2) return true;
-  return wid_bits >= 8 && max_items >= (((size_t)1 << h->g.lsize) >> 3);
+  if (wid_bits < 8) return false;
+  // a chunk pays for one pass over the table from about slots / 8 items on; with the window pass deferred over a
+  // batch of chunks (defer_budget) the table is streamed once per batch, so smaller chunks join an open batch and
+  // chunks from slots / 64 items on open one
+  if (h->defer_budget != 0 && (h->defer_open || max_items >= (((size_t)1 << h->g.lsize) >> 6))) return true;
+  return max_items >= (((size_t)1 << h->g.lsize) >> 3);
 }
 
 // device arrays of the FASTQ source for a chunk of buf_len bytes, at most rec_cap records / max_bases bases
@@ -402,7 +484,58 @@ struct part_source {
   int hashed = 0;
 };
 
-static int run_partitioned(qh_build* h, const part_source& src, size_t max_items) {
+// bytes the window buckets of one batch may take (0: no deferral)
+static size_t defer_budget_bytes(qh_build* h) {
+  if (h->defer_budget == 0) return 0;
+  if (h->defer_budget > 0) return (size_t)h->defer_budget;
+  if (!h->free_at_first_use) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    h->free_at_first_use = free_b + h->bins_cap[1];
+  }
+  const size_t by_table = (size_t)24 << h->g.lsize;  // three times the table
+  return by_table < h->free_at_first_use / 2 ? by_table : h->free_at_first_use / 2;
+}
+
+// The window pass over the open batch: every window is loaded (when the table holds entries), its bucket applied in
+// LDS, and streamed back; then the items that found no room in a bucket or a window go in one by one.
+// same_epoch: called at the end of the chunk that filled the buckets, whose counters are still being gathered in
+// d_meta; otherwise the chunk was collected already and d_meta is cleared but for its spill count.
+static int launch_flush(qh_build* h, bool same_epoch) {
+  if (!h->defer_open) return QH_OK;
+  QH_HIP(hipSetDevice(h->device));
+  if (!same_epoch && !h->pending) {
+    static_assert(offsetof(qh_meta, spill_count) == 32 && offsetof(qh_meta, instances) == 40, "qh_meta layout");
+    QH_HIP(hipMemsetAsync(h->d_meta, 0, offsetof(qh_meta, spill_count), h->stream));
+    QH_HIP(hipMemsetAsync(&h->d_meta->instances, 0, sizeof(qh_meta) - offsetof(qh_meta, instances), h->stream));
+  }
+  { int rc = ensure((void**)&h->d_wfail[0], &h->wfail_cap[0], (size_t)h->defer_nw * 4, "window flags"); if (rc) return rc; }
+  if (h->bspill_n) {  // what the direct insertion below cannot place goes to the overflow list: room for all of it
+    int rc = ensure((void**)&h->d_ovf[h->cur_ovf], &h->ovf_cap[h->cur_ovf], (h->bspill_n + h->defer_spill_cap + 1) * 8, "overflow list");
+    if (rc) return rc;
+  }
+  timing_begin(h, 3);
+  qh_launch_window_build(h->table, h->g, h->d_bins[1], h->defer_capw, h->d_bin_counts[1], h->defer_nw,
+                         (h->table_dirty ? 1 : 0) | (h->zero_pending ? 2 : 0), h->d_wfail[0], h->d_meta, h->stream);
+  timing_end(h, 3);
+  h->zero_pending = false;  // every window has been written
+  // items that overflowed a bucket (the last chunk's, then the batch's list): plain global-CAS insertion
+  qh_launch_insert_items(h->defer_spill, h->defer_spill_cap, reinterpret_cast<const unsigned long long*>(&h->d_meta->spill_count),
+                         0, 1, h->d_meta, h->g, h->table, h->d_ovf[h->cur_ovf], h->ovf_cap[h->cur_ovf] / 8, h->stream);
+  if (h->bspill_n)
+    qh_launch_insert_items(h->d_bspill, h->bspill_n, nullptr, 0, 1, h->d_meta, h->g, h->table, h->d_ovf[h->cur_ovf],
+                           h->ovf_cap[h->cur_ovf] / 8, h->stream);
+  h->bspill_n = 0;
+  QH_HIP(hipGetLastError());
+  h->defer_open = false;
+  h->defer_items = 0;
+  h->table_dirty = true;
+  h->pending = true;
+  h->st.window_passes += 1;
+  return QH_OK;
+}
+
+static int run_partitioned(qh_build* h, const part_source& src, size_t max_items, size_t est_items) {
   const qh_geom& g = h->g;
   const int wid_bits = g.lsize - QH_WINDOW_BITS;
   const uint32_t nw = 1u << wid_bits;
@@ -413,19 +546,47 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
   if (b1 > 12) b1 = 12;
   if (h->level1_bits >= 0 && h->level1_bits <= wid_bits && wid_bits - h->level1_bits <= 12) b1 = h->level1_bits;
   const int b2 = wid_bits - b1;
-  const size_t capw = max_items / nw + max_items / nw / 5 + 512;
-  const size_t cap1 = b2 ? max_items / ((size_t)1 << b1) + max_items / ((size_t)1 << b1) / 10 + 4096 : 0;
   int rc;
-  if ((rc = ensure((void**)&h->d_bins[1], &h->bins_cap[1], (size_t)nw * capw * 8, "window buckets"))) return rc;
-  // the counters are cleared by the segment kernel when there is one (FASTQ source), else by fills
+  // Window buckets: those of the open batch, or a new batch. A batch is sized for several chunks when the budget
+  // holds at least two of this size (the table is then streamed once for all of them, at the flush); otherwise
+  // for this chunk alone, which is flushed at once.
+  const bool open_new = !h->defer_open;
+  bool batch = !open_new;
+  size_t capw = h->defer_capw;
+  if (open_new) {
+    capw = max_items / nw + max_items / nw / 5 + 512;
+    const size_t budget = defer_budget_bytes(h);
+    if (budget) {
+      size_t per_w = budget / 8 / nw;
+      const uint64_t limit = qh_window_count_cap_limit(g);  // the counting window kernel needs counters above a bucket
+      if (limit && per_w > limit) per_w = (size_t)limit;
+      const size_t need_one = est_items / nw + est_items / nw / 5 + 512;
+      if (per_w >= 2 * need_one && ensure((void**)&h->d_bins[1], &h->bins_cap[1], (size_t)nw * per_w * 8, "window buckets") == QH_OK) {
+        // (with the buckets a list of a sixteenth of their capacity for what overflows single buckets)
+        if (ensure((void**)&h->d_bspill, &h->bspill_cap, ((size_t)nw * per_w / 16 + 65536) * 8, "batch spill list") == QH_OK) {
+          capw = per_w;
+          batch = true;
+        }
+      }
+    }
+    if (!batch && (rc = ensure((void**)&h->d_bins[1], &h->bins_cap[1], (size_t)nw * capw * 8, "window buckets"))) return rc;
+    h->defer_capw = capw;
+    h->defer_nw = nw;
+    h->defer_items = 0;
+    h->defer_cap_items = batch ? (uint64_t)nw * (capw - 512) / 6 * 5 : 0;  // windows differ: a fifth stays free
+    h->bspill_n = 0;
+  }
+  const size_t cap1 = b2 ? max_items / ((size_t)1 << b1) + max_items / ((size_t)1 << b1) / 10 + 4096 : 0;
+  // the counters are cleared by the segment kernel when there is one (FASTQ source), else by fills; the window
+  // buckets' counters only when a batch is opened: later chunks append
   const size_t wc_bytes = ((size_t)nw * 8 + 15) & ~(size_t)15, l1c_bytes = b2 ? (((size_t)8 << b1) * QH_COUNT_STRIDE + 15) & ~(size_t)15 : 0;
-  if ((rc = ensure((void**)&h->d_bin_counts[1], &h->bin_counts_cap[1], wc_bytes, "window bucket counts"))) return rc;
+  if (open_new && (rc = ensure((void**)&h->d_bin_counts[1], &h->bin_counts_cap[1], wc_bytes, "window bucket counts"))) return rc;
   if (b2) {
     if ((rc = ensure((void**)&h->d_bins[0], &h->bins_cap[0], ((size_t)cap1 << b1) * 8, "level-1 buckets"))) return rc;
     if ((rc = ensure((void**)&h->d_bin_counts[0], &h->bin_counts_cap[0], l1c_bytes, "level-1 bucket counts"))) return rc;
   }
   if (!src.fastq) {
-    QH_HIP(hipMemsetAsync(h->d_bin_counts[1], 0, wc_bytes, h->stream));
+    if (open_new) QH_HIP(hipMemsetAsync(h->d_bin_counts[1], 0, wc_bytes, h->stream));
     if (b2) QH_HIP(hipMemsetAsync(h->d_bin_counts[0], 0, l1c_bytes, h->stream));
   }
   // spill list = the idle overflow buffer; failures of its direct insertion go to the active one
@@ -433,6 +594,8 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
   if ((rc = ensure((void**)&h->d_ovf[other], &h->ovf_cap[other], (max_items + 1) * 8, "spill list"))) return rc;
   uint64_t* spill = h->d_ovf[other];
   const uint64_t spill_cap = h->ovf_cap[other] / 8;
+  h->defer_spill = spill;
+  h->defer_spill_cap = spill_cap;
 
   qh_part_dst win_dst = {h->d_bins[1], capw, h->d_bin_counts[1], g.shard_bits + QH_WINDOW_BITS, b2 ? b2 : wid_bits,
                          b2, spill, spill_cap, 1};
@@ -446,8 +609,8 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
     if ((rc = fastq_aux(h, src.fastq_len, src.rec_cap, src.max_bases, &aux))) return rc;
     timing_begin(h, 0);
     if (!src.planes_ready) qh_launch_text_planes(src.fastq, src.fastq_len, g, aux, h->stream);
-    qh_launch_segments(h->d_recs, (uint32_t)src.rec_cap, h->d_meta, g, aux, h->d_bin_counts[1], wc_bytes,
-                       b2 ? h->d_bin_counts[0] : nullptr, l1c_bytes, h->stream);
+    qh_launch_segments(h->d_recs, (uint32_t)src.rec_cap, h->d_meta, g, aux, open_new ? h->d_bin_counts[1] : nullptr,
+                       open_new ? wc_bytes : 0, b2 ? h->d_bin_counts[0] : nullptr, l1c_bytes, h->stream);
     timing_end(h, 0);
     timing_begin(h, 1);
     qh_launch_partition_fastq(aux, (uint32_t)src.rec_cap, h->d_meta, g, l1_dst, check_owner, h->stream);
@@ -462,17 +625,13 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
     qh_launch_partition_items(h->d_bins[0], cap1, h->d_bin_counts[0], QH_COUNT_STRIDE, 1u << b1, 0, 1, h->d_meta, g, win_dst, 0, 0, h->stream);
     timing_end(h, 2);
   }
-  timing_begin(h, 3);
-  qh_launch_window_build(h->table, g, h->d_bins[1], capw, h->d_bin_counts[1], nw,
-                         (h->table_dirty ? 1 : 0) | (h->zero_pending ? 2 : 0), spill,
-                         spill_cap, h->d_meta, h->stream);
-  timing_end(h, 3);
-  h->zero_pending = false;  // every window has been written
-  // items that overflowed a bucket or a window's reprobe limit: plain global-CAS insertion
-  qh_launch_insert_items(spill, spill_cap, reinterpret_cast<const unsigned long long*>(&h->d_meta->spill_count), 0, 1,
-                         h->d_meta, g, h->table, h->d_ovf[cur], h->ovf_cap[cur] / 8, h->stream);
   QH_HIP(hipGetLastError());
-  return QH_OK;
+  h->defer_open = true;
+  if (batch) {
+    h->pending_deferred = true;  // its item count joins the batch's when the chunk is collected
+    return QH_OK;
+  }
+  return launch_flush(h, true);
 }
 
 // ------------------------------------------------------------------ inputs
@@ -484,7 +643,8 @@ extern "C" int qh_build_add_fastq_device(qh_build* h, const void* dev_buf, size_
   if (len == 0) return QH_OK;
   if (!dev_buf || ((uintptr_t)dev_buf & 15)) return qh_fail(QH_EBADARG, "device chunk must be non-null and 16-byte aligned");
   if (len > kMaxChunk) return qh_fail(QH_EBADARG, "chunk larger than %zu bytes", kMaxChunk);
-  int rc = begin_chunk(h, len / 2);
+  const size_t est = est_fastq_items(h, len);
+  int rc = begin_chunk(h, len / 2, est);
   if (rc) return rc;
   const size_t ntiles = (len + QH_TILE_BYTES - 1) / QH_TILE_BYTES;
   const size_t rec_cap = len / 16 + 16;
@@ -504,17 +664,18 @@ extern "C" int qh_build_add_fastq_device(qh_build* h, const void* dev_buf, size_
     src.fastq_len = len;
     src.rec_cap = rec_cap;
     src.max_bases = len / 2;
-    if ((rc = run_partitioned(h, src, len / 2))) return rc;
+    if ((rc = run_partitioned(h, src, len / 2, est))) return rc;
   } else {
     if ((rc = materialize(h))) return rc;
     timing_begin(h);
     qh_launch_build_direct((const uint8_t*)dev_buf, h->d_recs, h->d_meta, h->g, h->table, h->d_ovf[h->cur_ovf],
                            h->ovf_cap[h->cur_ovf] / 8, h->stream);
     timing_end(h);
+    h->table_dirty = true;
   }
   QH_HIP(hipGetLastError());
   h->pending = true;
-  h->table_dirty = true;
+  h->pending_fastq_len = len;
   return QH_OK;
 }
 
@@ -533,7 +694,7 @@ extern "C" int qh_build_add_fastq(qh_build* h, const char* buf, size_t len) {
   if (len == 0) return QH_OK;
   if (!buf) return qh_fail(QH_EBADARG, "null chunk");
   if (len > kMaxChunk) return qh_fail(QH_EBADARG, "chunk larger than %zu bytes", kMaxChunk);
-  int rc = qh_build_sync(h);  // the staging buffer is reused: previous chunk must be done
+  int rc = sync_impl(h, false);  // the staging buffer is reused: the previous chunk must have been read (an open batch stays open)
   if (rc) return rc;
   QH_HIP(hipSetDevice(h->device));
   if ((rc = stage_chunk(h, buf, len, nullptr, 0, nullptr))) return rc;
@@ -544,7 +705,7 @@ extern "C" int qh_build_add_fastq(qh_build* h, const char* buf, size_t len) {
 
 static int submit_records(qh_build* h, const uint8_t* dev_buf, size_t buf_len, const qh_record* recs, size_t nrec,
                           size_t max_items) {
-  int rc = begin_chunk(h, max_items);
+  int rc = begin_chunk(h, max_items, max_items);
   if (rc) return rc;
   if ((rc = ensure((void**)&h->d_recs, &h->rec_cap, (nrec + 1) * 16, "record table"))) return rc;
   static_assert(sizeof(qh_record) == 16, "qh_record must match the device record");
@@ -558,15 +719,15 @@ static int submit_records(qh_build* h, const uint8_t* dev_buf, size_t buf_len, c
     src.fastq_len = buf_len;
     src.rec_cap = nrec;
     src.max_bases = max_items;
-    if ((rc = run_partitioned(h, src, max_items))) return rc;
+    if ((rc = run_partitioned(h, src, max_items, max_items))) return rc;
   } else {
     if ((rc = materialize(h))) return rc;
     timing_begin(h);
     qh_launch_build_direct(dev_buf, h->d_recs, h->d_meta, h->g, h->table, h->d_ovf[h->cur_ovf],
                            h->ovf_cap[h->cur_ovf] / 8, h->stream);
     timing_end(h);
+    h->table_dirty = true;
   }
-  h->table_dirty = true;
   QH_HIP(hipGetLastError());
   h->pending = true;
   return QH_OK;
@@ -676,7 +837,7 @@ extern "C" int qh_build_add_fastq_host_parsed(qh_build* h, const char* buf, size
   if (rc) return rc;
   if (consumed) *consumed = used;
   if (recs.empty()) return QH_OK;
-  if ((rc = qh_build_sync(h))) return rc;
+  if ((rc = sync_impl(h, false))) return rc;
   QH_HIP(hipSetDevice(h->device));
   size_t extra_off = 0;
   if ((rc = stage_chunk(h, buf, used, scratch.data(), scratch.size(), &extra_off))) return rc;
@@ -731,7 +892,7 @@ extern "C" int qh_build_add_fasta(qh_build* h, const char* buf, size_t len) {
   if (recs.empty()) return QH_OK;
   // one shared run of maximal qualities serves every record
   const std::string quals(maxlen, (char)127);
-  int rc = qh_build_sync(h);
+  int rc = sync_impl(h, false);
   if (rc) return rc;
   QH_HIP(hipSetDevice(h->device));
   size_t qoff = 0;
@@ -778,21 +939,21 @@ static int add_items_device(qh_build* h, const uint64_t* dev_items, size_t n, in
   if (!h) return qh_fail(QH_EBADARG, "null handle");
   if (n == 0) return QH_OK;
   if (!dev_items) return qh_fail(QH_EBADARG, "null items");
-  int rc = begin_chunk(h, n);
+  int rc = begin_chunk(h, n, n);
   if (rc) return rc;
   if (use_partition(h, n)) {
     part_source src;
     src.items = dev_items;
     src.n_items = n;
     src.hashed = hashed;
-    if ((rc = run_partitioned(h, src, n))) return rc;
+    if ((rc = run_partitioned(h, src, n, n))) return rc;
   } else {
     if ((rc = materialize(h))) return rc;
     timing_begin(h);
     qh_launch_insert_items(dev_items, n, nullptr, 1, hashed, h->d_meta, h->g, h->table, h->d_ovf[h->cur_ovf], h->ovf_cap[h->cur_ovf] / 8, h->stream);
     timing_end(h);
+    h->table_dirty = true;
   }
-  h->table_dirty = true;
   QH_HIP(hipGetLastError());
   h->pending = true;
   return QH_OK;
@@ -807,7 +968,7 @@ extern "C" int qh_build_add_mers(qh_build* h, const uint64_t* mers, const uint8_
     if (mers[i] & ~h->g.kmask) return qh_fail(QH_EBADARG, "mer %zu has bits above 2k", i);
     items[i] = (mers[i] << 1) | (quality[i] ? 1u : 0u);
   }
-  int rc = qh_build_sync(h);
+  int rc = sync_impl(h, false);
   if (rc) return rc;
   QH_HIP(hipSetDevice(h->device));
   if ((rc = ensure((void**)&h->d_items, &h->items_cap, n * 8, "item staging"))) return rc;
@@ -866,7 +1027,7 @@ extern "C" int qh_build_add_mers_device_noalloc(qh_build* h, const uint64_t* dev
   if (n > QH_NOALLOC_MAX_ITEMS)
     return qh_fail(QH_EBADARG, "qh_build_add_mers_device_noalloc takes at most %llu items per call (got %zu)",
                    (unsigned long long)QH_NOALLOC_MAX_ITEMS, n);
-  if (h->pending)
+  if (h->pending || h->defer_open)
     return qh_fail(QH_EBADARG, "a chunk of another entry point is in flight: call qh_build_sync first "
                                "(collecting it may have to grow the table, which allocates)");
   if (!h->noalloc_scratch) return qh_fail(QH_EHIP, "the scratch array was not resolved on device %d", h->device);
@@ -918,7 +1079,7 @@ extern "C" int qh_build_finish(qh_build* h, qh_build_stats* stats) {
 
 extern "C" int qh_build_reset(qh_build* h) {
   if (!h) return qh_fail(QH_EBADARG, "null handle");
-  if (h->pending) { int rc = qh_build_sync(h); if (rc && rc != QH_EFORMAT) return rc; }
+  if (h->pending) { int rc = sync_impl(h, false); if (rc && rc != QH_EFORMAT) return rc; }
   QH_HIP(hipSetDevice(h->device));
   h->zero_pending = true;  // cleared by the next partitioned chunk's window pass, or by materialize()
   const uint64_t slots = h->st.slots, grows = h->st.grows;
@@ -926,6 +1087,10 @@ extern "C" int qh_build_reset(qh_build* h) {
   h->st.slots = slots; h->st.grows = grows;
   h->failed = 0;
   h->table_dirty = false;
+  h->defer_open = false;  // what waited in the window buckets is dropped with the rest
+  h->defer_items = 0;
+  h->bspill_n = 0;
+  h->pending_deferred = false;
   return QH_OK;
 }
 

@@ -33,6 +33,22 @@ struct qh_build {
   int mode = 0;               // 0 auto, 1 direct global-CAS build, 2 radix-partitioned LDS build
   int level1_bits = -1;       // -1 auto: buckets of the first partition level (QH_LEVEL1_BITS)
   int cur_ovf = 0;
+  // Deferred window pass: the window buckets (d_bins[1]) of successive partitioned chunks accumulate in HBM and the
+  // table is streamed once per BATCH of chunks instead of once per chunk (qh_build.hip: run_partitioned / launch_flush)
+  long long defer_budget = -1;   // bytes the window buckets of a batch may take: -1 automatic, 0 = every chunk is flushed
+  size_t free_at_first_use = 0;  // free device memory when the first batch was sized (automatic budget)
+  bool defer_open = false;       // the window buckets hold items that are not in the table yet
+  size_t defer_capw = 0;         // capacity of a window bucket in the open batch
+  uint32_t defer_nw = 0;         // windows of the table the batch was opened for
+  uint64_t defer_items = 0;      // items of the batch's chunks collected so far
+  uint64_t defer_cap_items = 0;  // items the batch takes before it is flushed
+  uint64_t* defer_spill = nullptr; uint64_t defer_spill_cap = 0;  // spill list of the batch's last chunk
+  uint64_t* d_bspill = nullptr; size_t bspill_cap = 0;           // items that overflowed a bucket, of the whole batch (bytes)
+  uint64_t bspill_n = 0;
+  uint32_t* d_wfail[2] = {nullptr, nullptr}; size_t wfail_cap[2] = {0, 0};  // per window: the pass left it as it was
+  bool pending_deferred = false; // the chunk in flight went into the open batch
+  size_t pending_fastq_len = 0;  // bytes of the FASTQ chunk in flight (items per byte are learnt at collection)
+  double items_per_byte = 0;     // largest ratio seen so far: sizes a batch better than the len / 2 bound
   qh_meta* d_meta = nullptr;
   qh_meta* h_meta = nullptr;  // pinned mirror
   qh_build_stats st;

@@ -21,6 +21,8 @@ struct qh_meta {
   uint64_t foreign;      // items owned by another shard (dropped)
   uint64_t dump_count;   // cursor of k_dump
   uint64_t stat_distinct, stat_total;
+  uint32_t win_failed;   // windows of the last pass that were left as they were (an item hit the reprobe limit)
+  uint32_t reserved_;
 };
 
 enum { QH_FMT_LINES_MOD4 = 1, QH_FMT_NO_AT = 2, QH_FMT_NO_PLUS = 4, QH_FMT_LEN_MISMATCH = 8,
@@ -98,9 +100,18 @@ void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsign
                                const qh_part_dst& d, int check_owner, int count_instances, hipStream_t s);
 // table_state: bit 0 = the table holds entries (load each window first), bit 1 = the table has not
 // been cleared yet (windows without items must be zeroed here)
+// A window whose items do not all find a slot within the reprobe limit is left as it was: fail[w] = 1 (0 for every
+// other window) and meta->win_failed counts them; qh_launch_window_redo runs those buckets again on the grown table.
 void qh_launch_window_build(uint64_t* table, const qh_geom& g, const uint64_t* items, uint64_t cap,
-                            const unsigned long long* counts, uint32_t n_windows, int table_state, uint64_t* spill,
-                            uint64_t spill_cap, qh_meta* meta, hipStream_t s);
+                            const unsigned long long* counts, uint32_t n_windows, int table_state, uint32_t* fail,
+                            qh_meta* meta, hipStream_t s);
+void qh_launch_window_redo(uint64_t* table, const qh_geom& g, const uint64_t* items, uint64_t cap,
+                           const unsigned long long* counts, uint32_t n_buckets, uint32_t n_windows, uint32_t* fail,
+                           const uint32_t* prev_fail, uint32_t n_prev, qh_meta* meta, hipStream_t s);
+
+// largest bucket capacity for which qh_launch_window_build still takes its fastest counting kernel at this geometry
+// (counters must stay above a bucket's fill); 0 = the capacity does not change the kernel
+uint64_t qh_window_count_cap_limit(const qh_geom& g);
 
 // --- read side ------------------------------------------------------------------------
 void qh_launch_lookup(const uint64_t* table, const qh_geom& g, const uint64_t* mers, uint64_t n,

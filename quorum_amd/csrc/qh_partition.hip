@@ -536,23 +536,37 @@ void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsign
 // lane offers, so the chain state is 32-bit and the round is ~25 VALU instructions. The kernel
 // is VALU-issue bound (16-lane SIMDs, 4 waves each), so instructions per round are what count:
 // ring bookkeeping is kept wave-uniform in SGPRs and the round is written without branches.
-template <bool NARROW>
+//
+// A window is a TRANSACTION: when one of its items finds no slot within the reprobe limit, the window is not written
+// back (the table keeps what it held before the pass, or zeros when its clearing was left to this pass), fail[w] is
+// set and meta->win_failed counts it; the bucket stays as it was. The host then doubles the table and runs the failed
+// windows' buckets again (FILTER: a window of the grown table takes, from the bucket of the window it descends from,
+// the items whose hash names it). Nothing is queued per item, so a batch of any size needs no overflow memory.
+template <bool NARROW, bool FILTER>
 __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restrict__ table, const qh_geom g,
                                                              const uint64_t* __restrict__ items, uint64_t cap,
                                                              const unsigned long long* __restrict__ counts,
-                                                             int table_dirty, uint64_t* __restrict__ spill,
-                                                             uint64_t spill_cap, qh_meta* __restrict__ meta) {
+                                                             int table_dirty, qh_meta* __restrict__ meta,
+                                                             uint32_t* __restrict__ fail,
+                                                             const uint32_t* __restrict__ prev_fail, uint32_t prev_mask,
+                                                             uint32_t bucket_mask, uint32_t win_mask) {
   __shared__ uint64_t win[1u << QH_WINDOW_BITS];
   __shared__ uint64_t ring[QP_WAVES][QW_RING];  // window + rings = half of the CU's LDS: two workgroups per CU
   uint32_t* wnew = reinterpret_cast<uint32_t*>(&ring[0][0]);  // reused once the rings have drained
   const uint32_t w = blockIdx.x;
-  uint64_t n = counts[w];
+  const uint32_t bkt = FILTER ? w & bucket_mask : w;
+  if (FILTER && prev_fail[w & prev_mask] == 0) {  // the window this one descends from went through
+    if (threadIdx.x == 0) fail[w] = 0;
+    return;
+  }
+  uint64_t n = counts[bkt];
   if (n > cap) n = cap;
   if (n == 0) {  // nothing to add: the window stays as it is, or is cleared when the table's clearing was left to us
     if (table_dirty & 2) {
       uint4* z = reinterpret_cast<uint4*>(table + ((uint64_t)w << QH_WINDOW_BITS));
       for (uint32_t i = threadIdx.x; i < (1u << QH_WINDOW_BITS) / 2; i += QP_THREADS) z[i] = make_uint4(0, 0, 0, 0);
     }
+    if (threadIdx.x == 0) fail[w] = 0;
     return;
   }
   const int tid = threadIdx.x, lane = tid & 63;
@@ -561,10 +575,11 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
   const uint32_t seg = (uint32_t)((n + QP_WAVES - 1) / QP_WAVES);
   const uint32_t s0 = (uint32_t)(((uint64_t)wave * seg) < n ? (uint64_t)wave * seg : n);
   const uint32_t seg_n = (uint32_t)((uint64_t)s0 + seg <= n ? seg : n - s0);
-  const uint64_t* src = items + (uint64_t)w * cap + s0;
+  const uint64_t* src = items + (uint64_t)bkt * cap + s0;
   // first 64 items in flight while the window is brought into LDS; items [tail, tail + 64) are on request
   // whenever tail < seg_n
   uint64_t pend = (uint32_t)lane < seg_n ? src[lane] : QP_NONE;
+  bool lane_fail = false;
   uint4* tw = reinterpret_cast<uint4*>(table + ((uint64_t)w << QH_WINDOW_BITS));
   uint4* lw = reinterpret_cast<uint4*>(win);
   const uint32_t nvec = (1u << QH_WINDOW_BITS) / 2;  // 16-byte pieces
@@ -614,6 +629,8 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
       if (!live && rank < give) {
         v = __hip_atomic_load(&myring[(head + rank) & (QW_RING - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const uint64_t h = v >> 1;
+        // (FILTER: the bucket was made for a smaller table; items of this window's siblings stay where they are)
+        const bool ours = !FILTER || ((uint32_t)((h >> g.shard_bits) >> QH_WINDOW_BITS) & win_mask) == w;
         pos = (uint32_t)(h >> g.shard_bits) & wmask;
         // want = (remainder | probe+1) << vbits: our key's slot word at this probe with a zero value
         want = (((gsize >= 64 ? 0 : (h >> gsize)) << g.pbits) | 1) << g.vbits;
@@ -628,7 +645,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
           cmp = 0;
           nw = want | 2u | q;
         }
-        live = true;
+        live = ours;
       }
       head += give;
     }
@@ -650,11 +667,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
         n_new += (uint32_t)(swapped & (cmp_lo == 0));
         const bool upd = !swapped & match & can;  // update round next
         const bool probe = !swapped & !match;     // another key: next probe
-        if (probe && left == 0) {                 // reprobe limit: leave it to the direct path
-          const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(&meta->spill_count), 1ull);
-          if (at < spill_cap) spill[at] = v;
-          else meta->ovf_lost = 1;
-        }
+        lane_fail |= probe & (left == 0);         // reprobe limit: the window fails as a whole
         const bool go = probe & (left != 0);
         pos = go ? (pos + 1) & wmask : pos;
         left -= (uint32_t)go;
@@ -676,10 +689,8 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
             cmp = prev;
             nw = want | nv;
           }
-        } else if (left == 0) {                     // reprobe limit: leave it to the direct path
-          const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(&meta->spill_count), 1ull);
-          if (at < spill_cap) spill[at] = v;
-          else meta->ovf_lost = 1;
+        } else if (left == 0) {                     // reprobe limit: the window fails as a whole
+          lane_fail = true;
           live = false;
         } else {                                    // another key: next probe, claim round again
           --left;
@@ -692,15 +703,26 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
     }
   }
   n_new = wave_sum_u32(n_new);
+  const bool wave_fail = __ballot(lane_fail) != 0;
   __syncthreads();  // every chain has ended: the window is final and the rings are free
-  if (lane == 0) wnew[wave] = n_new;
-#pragma unroll
-  for (uint32_t i = 0; i < nvec / QP_THREADS; ++i) tw[i * QP_THREADS + tid] = lw[i * QP_THREADS + tid];
+  if (lane == 0) { wnew[wave] = n_new; wnew[QP_WAVES + wave] = wave_fail ? 1u : 0u; }
   __syncthreads();
+  bool failed = false;
+#pragma unroll
+  for (int i = 0; i < QP_WAVES; ++i) failed |= wnew[QP_WAVES + i] != 0;
+  if (!failed) {
+#pragma unroll
+    for (uint32_t i = 0; i < nvec / QP_THREADS; ++i) tw[i * QP_THREADS + tid] = lw[i * QP_THREADS + tid];
+  } else if (table_dirty & 2) {
+#pragma unroll
+    for (uint32_t i = 0; i < nvec / QP_THREADS; ++i) tw[i * QP_THREADS + tid] = make_uint4(0, 0, 0, 0);
+  }
   if (tid == 0) {
     uint32_t t = 0;
     for (int i = 0; i < QP_WAVES; ++i) t += wnew[i];
-    if (t) atomicAdd(reinterpret_cast<unsigned long long*>(&meta->new_keys), (unsigned long long)t);
+    if (t && !failed) atomicAdd(reinterpret_cast<unsigned long long*>(&meta->new_keys), (unsigned long long)t);
+    fail[w] = failed ? 1u : 0u;
+    if (failed) atomicAdd(&meta->win_failed, 1u);
   }
 }
 
@@ -733,8 +755,8 @@ __global__ __launch_bounds__(QP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
                                                              const uint64_t* __restrict__ items, uint64_t cap,
                                                              const unsigned long long* __restrict__ counts,
                                                              uint32_t n_windows, int table_dirty,
-                                                             uint64_t* __restrict__ spill, uint64_t spill_cap,
-                                                             qh_meta* __restrict__ meta, int cb_arg) {
+                                                             qh_meta* __restrict__ meta, int cb_arg,
+                                                             uint32_t* __restrict__ fail) {
   typedef typename std::conditional<CB16, uint32_t, uint64_t>::type tag_t;  // tag = remainder | probe + 1
   __shared__ uint64_t win[1u << QH_WINDOW_BITS];
   __shared__ uint64_t ring[QP_WAVES][QW_RING];  // window + rings = half of the CU's LDS: two workgroups per CU
@@ -790,10 +812,15 @@ __global__ __launch_bounds__(QP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     if (n == 0) {  // nothing to add: the window stays as it is, or is cleared when the table's clearing was left to us
       if (table_dirty & 2)
         for (uint32_t i = tid; i < nvec; i += QP_THREADS) tw[i] = make_uint4(0, 0, 0, 0);
+      if (tid == 0) fail[w] = 0;
       n = n_next;
       open_bucket(w + gridDim.x, n);
       continue;
     }
+    // The window's flag starts at 0 here; a lane whose item runs out of probes sets it (a plain store, on a path
+    // nearly never taken) and every wave reads it back after the window's last barrier: the failure costs the
+    // loop no register and no instruction.
+    if (tid == 0) __hip_atomic_store(&fail[w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // every thread fills the pieces of the window it wrote out for the previous one: no barrier in between
     if (table_dirty & 1) {
 #pragma unroll
@@ -888,33 +915,41 @@ __global__ __launch_bounds__(QP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         } else {
           // another key lives here: withdraw and probe on
           __hip_atomic_fetch_sub(slot, (unsigned long long)inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          {
-            if (left == 0) {  // reprobe limit: leave it to the direct path
-              const uint32_t probe = ((uint32_t)T & ((1u << g.pbits) - 1)) - 1;
-              const uint64_t home = ((uint64_t)w << QH_WINDOW_BITS) | ((pos - probe) & wmask);
-              const uint64_t h = (gsize >= 64 ? 0 : ((uint64_t)(T >> g.pbits) << gsize)) | (home << g.shard_bits) |
-                                 (uint64_t)g.shard_id;
-              const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(&meta->spill_count), 1ull);
-              if (at < spill_cap) spill[at] = (h << 1) | (inc != 1u ? 1u : 0u);
-              else meta->ovf_lost = 1;
-            }
-            --left;
-            pos = (pos + 1) & wmask;
-            ++T;
-          }
+          if (__builtin_expect(left == 0, 0))  // reprobe limit: the window fails as a whole (see k_window_build)
+            __hip_atomic_store(&fail[w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          --left;
+          pos = (pos + 1) & wmask;
+          ++T;
         }
       }
     }
-    __syncthreads();  // every chain of the window has ended
+    __syncthreads();  // every chain of the window has ended (and every store to its flag has been made)
+    const bool failed = __hip_atomic_load(&fail[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     n = n_next;
     open_bucket(w + gridDim.x, n);  // the next bucket's first items travel while this window is written out
+    typedef uint32_t qh_v4u __attribute__((ext_vector_type(4)));
+    if (__builtin_expect(!failed, 1)) {
 #pragma unroll
-    for (uint32_t i = 0; i < nvec / QP_THREADS; ++i) {
-      const uint4 x = lw[i * QP_THREADS + tid];
-      const uint64_t a = to_table(((uint64_t)x.y << 32) | x.x), b = to_table(((uint64_t)x.w << 32) | x.z);
-      typedef uint32_t qh_v4u __attribute__((ext_vector_type(4)));
-      const qh_v4u o = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
-      __builtin_nontemporal_store(o, reinterpret_cast<qh_v4u*>(tw + i * QP_THREADS + tid));
+      for (uint32_t i = 0; i < nvec / QP_THREADS; ++i) {
+        const uint4 x = lw[i * QP_THREADS + tid];
+        const uint64_t a = to_table(((uint64_t)x.y << 32) | x.x), b = to_table(((uint64_t)x.w << 32) | x.z);
+        const qh_v4u o = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+        __builtin_nontemporal_store(o, reinterpret_cast<qh_v4u*>(tw + i * QP_THREADS + tid));
+      }
+    } else {
+      // the window stays as it was. The slots claimed in it were counted as new keys: taken back here (tags in
+      // LDS now, minus the entries the window held when it was loaded), the pass that runs the bucket again
+      // counts them when they stay
+      int32_t claimed = 0;
+      for (uint32_t i = tid; i < (1u << QH_WINDOW_BITS); i += QP_THREADS) {
+        claimed += (win[i] >> tagshift) != 0 ? 1 : 0;
+        if (table_dirty & 1) claimed -= table[((uint64_t)w << QH_WINDOW_BITS) + i] != 0 ? 1 : 0;
+      }
+      atomicAdd(reinterpret_cast<unsigned long long*>(&meta->new_keys), (unsigned long long)(long long)(-claimed));
+      if (table_dirty & 2)
+        for (uint32_t i = tid; i < nvec; i += QP_THREADS) tw[i] = make_uint4(0, 0, 0, 0);
+      if (tid == 0) atomicAdd(&meta->win_failed, 1u);
+      __syncthreads();  // the window in LDS has been read by all before the next one is loaded over it
     }
   }
   n_new = wave_sum_u32(n_new);
@@ -928,9 +963,18 @@ __global__ __launch_bounds__(QP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   }
 }
 
+uint64_t qh_window_count_cap_limit(const qh_geom& g) {
+  const int tagbits = g.rbits + g.pbits;
+  int cb = (64 - tagbits) / 2;
+  if (cb > 31) cb = 31;
+  if (tagbits > 64 - (QH_WINDOW_BITS + 1) || cb < 10 || (1ull << cb) <= g.max_val + 2) return 0;  // compare-and-swap kernel
+  if (tagbits <= 32 && 65536ull > g.max_val + 2 + 1024) return 65536ull - g.max_val - 2;          // 16-bit counters
+  return (1ull << cb) - g.max_val - 2;
+}
+
 void qh_launch_window_build(uint64_t* table, const qh_geom& g, const uint64_t* items, uint64_t cap,
-                            const unsigned long long* counts, uint32_t n_windows, int table_dirty, uint64_t* spill,
-                            uint64_t spill_cap, qh_meta* meta, hipStream_t s) {
+                            const unsigned long long* counts, uint32_t n_windows, int table_dirty, uint32_t* fail,
+                            qh_meta* meta, hipStream_t s) {
   // counting form when [tag | H | L] fits 64 bits with counters that can hold a whole bucket
   const char* force = getenv("QH_WINDOW_KERNEL");  // A/B tests: "cas" compare-and-swap kernels, "count" generic counters
   const int tagbits = g.rbits + g.pbits;
@@ -947,16 +991,25 @@ void qh_launch_window_build(uint64_t* table, const qh_geom& g, const uint64_t* i
     const bool cb16 = tagbits <= 32 && 65536ull > cap + g.max_val + 1 && !(force && !strcmp(force, "count"));
     if (cb16)
       hipLaunchKernelGGL(k_window_count<true>, dim3(grid), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
-                         n_windows, table_dirty, spill, spill_cap, meta, 16);
+                         n_windows, table_dirty, meta, 16, fail);
     else
       hipLaunchKernelGGL(k_window_count<false>, dim3(grid), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
-                         n_windows, table_dirty, spill, spill_cap, meta, cb);
+                         n_windows, table_dirty, meta, cb, fail);
     return;
   }
   if (g.vbits + g.pbits <= 32)
-    hipLaunchKernelGGL(k_window_build<true>, dim3(n_windows), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
-                       table_dirty, spill, spill_cap, meta);
+    hipLaunchKernelGGL((k_window_build<true, false>), dim3(n_windows), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
+                       table_dirty, meta, fail, nullptr, 0u, 0u, 0u);
   else
-    hipLaunchKernelGGL(k_window_build<false>, dim3(n_windows), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
-                       table_dirty, spill, spill_cap, meta);
+    hipLaunchKernelGGL((k_window_build<false, false>), dim3(n_windows), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
+                       table_dirty, meta, fail, nullptr, 0u, 0u, 0u);
+}
+
+// The failed windows of a pass again, after the table has grown: buckets made for n_buckets windows, table of
+// n_windows (a power-of-two multiple); prev_fail has the flags of the pass before (n_prev windows).
+void qh_launch_window_redo(uint64_t* table, const qh_geom& g, const uint64_t* items, uint64_t cap,
+                           const unsigned long long* counts, uint32_t n_buckets, uint32_t n_windows, uint32_t* fail,
+                           const uint32_t* prev_fail, uint32_t n_prev, qh_meta* meta, hipStream_t s) {
+  hipLaunchKernelGGL((k_window_build<false, true>), dim3(n_windows), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
+                     1, meta, fail, prev_fail, n_prev - 1u, n_buckets - 1u, n_windows - 1u);
 }

@@ -148,6 +148,11 @@ class HashWithQuality:
     def set_mode(self, mode="auto", level1_bits=-1):
         check(lib.qh_build_set_mode(self._h, {"auto": 0, "direct": 1, "partition": 2}[mode], level1_bits))
 
+    def set_defer(self, max_bytes=-1):
+        """memory the window buckets of a batch of partitioned chunks may take before the table is streamed
+        (0: every chunk at once, negative: automatic)"""
+        check(lib.qh_build_set_defer(self._h, max_bytes))
+
     def reset(self):
         check(lib.qh_build_reset(self._h))
 
