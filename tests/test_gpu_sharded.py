@@ -113,6 +113,9 @@ def test_two_rank_bench_rehearsal():
     # 2 ranks x 200k reads x (100-24+1) windows, minus the windows that contain an N
     assert 0.97 * 2 * 200000 * 77 < d["config"]["insertions_per_step"] <= 2 * 200000 * 77
     assert d["config"]["pieces_per_gpu"] == 3
+    # the run checked itself: both shards' content against a single-table build of the same reads
+    assert d["content_check"]["ok"] is True and d["content_check"]["reads_per_rank"] == 60000
+    assert d["exchange_message_cap"] == 8 << 26 and "large_message_ok" not in d   # (the large message is RCCL's test)
 
 
 def _pipeline_rank(rank, world, port, outdir):
