@@ -258,14 +258,18 @@ static int grow_table(qh_build* h, int target_lsize) {
 // What a chunk or a window pass could not place: items that hit the reprobe limit on the direct path wait in the
 // overflow list, windows that an item overflowed were left as they were with their buckets intact (k_window_build).
 // The table doubles (handle_full_ary, mer_database.hpp:137-187) and both are run again, until nothing is left.
-static int resolve_full(qh_build* h, uint64_t n_ovf, uint32_t n_winfail) {
+static int resolve_full(qh_build* h, uint64_t n_ovf, uint32_t n_winfail, uint32_t n_winhot) {
   uint32_t n_prev = h->defer_nw;  // windows of the pass whose flags are in d_wfail[wf]
   int wf = 0;
-  while (n_ovf || n_winfail) {
+  while (n_ovf || n_winfail || n_winhot) {
     const int src = h->cur_ovf, dst = src ^ 1;
     int rc;
     if (n_ovf && (rc = ensure((void**)&h->d_ovf[dst], &h->ovf_cap[dst], n_ovf * 8, "overflow list"))) return rc;
-    if ((rc = grow_table(h, h->g.lsize + 1))) return rc;
+    // windows that only met a hot key (watched counters) run again at this table size, with the compare-and-swap
+    // kernel; what is full grows first
+    if ((n_ovf || n_winfail) && (rc = grow_table(h, h->g.lsize + 1))) return rc;
+    n_winfail += n_winhot;
+    n_winhot = 0;
     QH_HIP(hipMemsetAsync(h->d_meta, 0, sizeof(qh_meta), h->stream));
     if (n_ovf)
       qh_launch_insert_items(h->d_ovf[src], n_ovf, nullptr, 0, 1, h->d_meta, h->g, h->table, h->d_ovf[dst], h->ovf_cap[dst] / 8, h->stream);
@@ -358,9 +362,9 @@ static int sync_impl(qh_build* h, bool flush) {
       } else if ((rc = launch_flush(h, false)) == QH_OK) {
         continue;
       }
-    } else if (m.ovf_count || m.win_failed) {
+    } else if (m.ovf_count || m.win_failed || m.win_hot) {
       if (h->defer_open) rc = qh_fail(QH_EHIP, "internal: overflow items while a deferred batch is open");
-      else rc = resolve_full(h, m.ovf_count, m.win_failed);
+      else rc = resolve_full(h, m.ovf_count, m.win_failed, m.win_hot);
     }
     if (rc) { h->failed = rc; h->failed_msg = g_last_error; }
     return rc;

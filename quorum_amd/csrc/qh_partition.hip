@@ -750,13 +750,20 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
 // kernel is bound by the instructions a wave issues per round (one workgroup of 16 waves per CU, LDS, VALU
 // and HBM each about half used), so the round is kept short: a 128-entry ring whose refill and next request
 // are one step, liveness folded into the probe counter, the increment decoded once per item.
-template <bool CB16>
+//
+// GUARD: counters narrower than a bucket (k = 31 at tables below 2^32 slots: 41 tag bits leave 11-bit counters for
+// buckets of thousands). A counter moves by one per add or withdrawal, so before a field can carry into its neighbour
+// some add must return `hot_limit` = 2^cb - 1 - 1024 (every lane of the workgroup has at most one add in flight): the
+// lane that sees it marks the window as failed-hot (fail[w] = 2) and the window is left as it was, like one that ran
+// out of probes; the host runs such windows again with the compare-and-swap kernel, at the same table size. A key
+// must be seen a thousand times in one bucket for that: the reads' own coverage never does it, repeats may.
+template <bool CB16, bool GUARD = false>
 __global__ __launch_bounds__(QP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_window_count(uint64_t* __restrict__ table, const qh_geom g,
                                                              const uint64_t* __restrict__ items, uint64_t cap,
                                                              const unsigned long long* __restrict__ counts,
                                                              uint32_t n_windows, int table_dirty,
                                                              qh_meta* __restrict__ meta, int cb_arg,
-                                                             uint32_t* __restrict__ fail) {
+                                                             uint32_t* __restrict__ fail, uint32_t hot_limit) {
   typedef typename std::conditional<CB16, uint32_t, uint64_t>::type tag_t;  // tag = remainder | probe + 1
   __shared__ uint64_t win[1u << QH_WINDOW_BITS];
   __shared__ uint64_t ring[QP_WAVES][QW_RING];  // window + rings = half of the CU's LDS: two workgroups per CU
@@ -842,6 +849,7 @@ __global__ __launch_bounds__(QP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     tag_t T = 0;
     uint32_t pos = 0, inc = 1;
     int left = -1;
+    const uint32_t n_new_before = n_new;  // (GUARD: a failed window's LDS image may be corrupt: its claims are forgotten)
 
     for (;;) {
       uint32_t avail = tail - head;
@@ -885,6 +893,11 @@ __global__ __launch_bounds__(QP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
       if (left >= 0) {
         unsigned long long* slot = reinterpret_cast<unsigned long long*>(&win[pos]);
         const uint64_t old = atomicAdd(slot, (unsigned long long)inc);
+        if (GUARD) {
+          const uint32_t field = (inc == 1u ? (uint32_t)old : (uint32_t)(old >> cb)) & (uint32_t)cmask;
+          if (__builtin_expect(field >= hot_limit, 0))
+            __hip_atomic_store(&fail[w], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         tag_t t = CB16 ? (tag_t)(old >> 32) : (tag_t)(old >> tagshift);
         if (t == 0) {  // a free slot: claim it, sighting included
           // Tried again in place while only counters move: every failure is then another chain's add or
@@ -924,7 +937,8 @@ __global__ __launch_bounds__(QP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
       }
     }
     __syncthreads();  // every chain of the window has ended (and every store to its flag has been made)
-    const bool failed = __hip_atomic_load(&fail[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    const uint32_t fail_kind = __hip_atomic_load(&fail[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool failed = fail_kind != 0;
     n = n_next;
     open_bucket(w + gridDim.x, n);  // the next bucket's first items travel while this window is written out
     typedef uint32_t qh_v4u __attribute__((ext_vector_type(4)));
@@ -940,15 +954,19 @@ __global__ __launch_bounds__(QP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
       // the window stays as it was. The slots claimed in it were counted as new keys: taken back here (tags in
       // LDS now, minus the entries the window held when it was loaded), the pass that runs the bucket again
       // counts them when they stay
-      int32_t claimed = 0;
-      for (uint32_t i = tid; i < (1u << QH_WINDOW_BITS); i += QP_THREADS) {
-        claimed += (win[i] >> tagshift) != 0 ? 1 : 0;
-        if (table_dirty & 1) claimed -= table[((uint64_t)w << QH_WINDOW_BITS) + i] != 0 ? 1 : 0;
+      if (GUARD) {
+        n_new = n_new_before;
+      } else {
+        int32_t claimed = 0;
+        for (uint32_t i = tid; i < (1u << QH_WINDOW_BITS); i += QP_THREADS) {
+          claimed += (win[i] >> tagshift) != 0 ? 1 : 0;
+          if (table_dirty & 1) claimed -= table[((uint64_t)w << QH_WINDOW_BITS) + i] != 0 ? 1 : 0;
+        }
+        atomicAdd(reinterpret_cast<unsigned long long*>(&meta->new_keys), (unsigned long long)(long long)(-claimed));
       }
-      atomicAdd(reinterpret_cast<unsigned long long*>(&meta->new_keys), (unsigned long long)(long long)(-claimed));
       if (table_dirty & 2)
         for (uint32_t i = tid; i < nvec; i += QP_THREADS) tw[i] = make_uint4(0, 0, 0, 0);
-      if (tid == 0) atomicAdd(&meta->win_failed, 1u);
+      if (tid == 0) atomicAdd(fail_kind == 2u ? &meta->win_hot : &meta->win_failed, 1u);
       __syncthreads();  // the window in LDS has been read by all before the next one is loaded over it
     }
   }
@@ -969,6 +987,7 @@ uint64_t qh_window_count_cap_limit(const qh_geom& g) {
   if (cb > 31) cb = 31;
   if (tagbits > 64 - (QH_WINDOW_BITS + 1) || cb < 10 || (1ull << cb) <= g.max_val + 2) return 0;  // compare-and-swap kernel
   if (tagbits <= 32 && 65536ull > g.max_val + 2 + 1024) return 65536ull - g.max_val - 2;          // 16-bit counters
+  if (cb >= 11 && (1ull << cb) > 1025 + 2 * (g.max_val + 1)) return 0;                             // watched counters: any bucket
   return (1ull << cb) - g.max_val - 2;
 }
 
@@ -981,20 +1000,26 @@ void qh_launch_window_build(uint64_t* table, const qh_geom& g, const uint64_t* i
   int cb = (64 - tagbits) / 2;
   if (cb > 31) cb = 31;
   // (the tag must also fit a ring entry beside the position and the quality bit; 2^cb > max_val is implied)
-  const bool fits = tagbits <= 64 - (QH_WINDOW_BITS + 1) && cb >= 10 && (1ull << cb) > cap + g.max_val + 1;
-  if (fits && !(force && !strcmp(force, "cas"))) {
+  const bool ring_ok = tagbits <= 64 - (QH_WINDOW_BITS + 1);
+  const bool fits = ring_ok && cb >= 10 && (1ull << cb) > cap + g.max_val + 1;
+  // counters narrower than a bucket, but wide enough to be watched (see GUARD)
+  const bool guard = !fits && ring_ok && cb >= 11 && (1ull << cb) > 1025 + 2 * (g.max_val + 1) && !(force && !strcmp(force, "noguard"));
+  if ((fits || guard) && !(force && !strcmp(force, "cas"))) {
     // one workgroup per CU walks the windows (see the kernel): QH_WINDOW_GRID overrides the grid for A/B tests
     const char* gs = getenv("QH_WINDOW_GRID");
     uint32_t grid = gs ? (uint32_t)atoi(gs) : 512u;
     if (grid == 0 || grid > n_windows) grid = n_windows;
     // 16-bit counters: the tag is the high word ("count": the generic form even then)
-    const bool cb16 = tagbits <= 32 && 65536ull > cap + g.max_val + 1 && !(force && !strcmp(force, "count"));
+    const bool cb16 = fits && tagbits <= 32 && 65536ull > cap + g.max_val + 1 && !(force && !strcmp(force, "count"));
     if (cb16)
-      hipLaunchKernelGGL(k_window_count<true>, dim3(grid), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
-                         n_windows, table_dirty, meta, 16, fail);
+      hipLaunchKernelGGL((k_window_count<true, false>), dim3(grid), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
+                         n_windows, table_dirty, meta, 16, fail, 0u);
+    else if (fits)
+      hipLaunchKernelGGL((k_window_count<false, false>), dim3(grid), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
+                         n_windows, table_dirty, meta, cb, fail, 0u);
     else
-      hipLaunchKernelGGL(k_window_count<false>, dim3(grid), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
-                         n_windows, table_dirty, meta, cb, fail);
+      hipLaunchKernelGGL((k_window_count<false, true>), dim3(grid), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
+                         n_windows, table_dirty, meta, cb, fail, (uint32_t)((1u << cb) - 1u - 1024u));
     return;
   }
   if (g.vbits + g.pbits <= 32)

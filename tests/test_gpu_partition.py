@@ -79,6 +79,36 @@ def test_window_kernels_agree(k, bits, size, monkeypatch):
         h.close()
 
 
+def test_watched_counters_for_wide_tags(monkeypatch):
+    """k = 31 into 2^28 slots: 42 tag bits leave 11-bit counters, fewer than a bucket of this chunk holds (3.9 K). The
+    counting kernel then watches its counters (GUARD): a window where a key is seen a thousand times -- here the one
+    with 360 000 poly-A sightings -- is left as it was and run again by the compare-and-swap kernel; every other
+    window counts. Same content as the compare-and-swap kernel alone and as the oracle."""
+    from quorum_amd import synth
+    k, bits, L = 31, 7, 150
+    g = synth.make_genome(2_000_000, seed=31)
+    fq = synth.make_fastq(g, 600_000, L, err=0.01, seed=32, tails=True).tobytes()
+    fq += b"".join(b"@polyA%d\n" % i + b"A" * L + b"\n+\n" + b"I" * L + b"\n" for i in range(3000))
+    db = po.OracleDB(1 << 27, k, bits)
+    n = db.add_fastq(fq, 38, threads=8)
+    om, ov = db.sorted_dump()
+    passes = {}
+    for kernel in ("", "noguard"):
+        monkeypatch.setenv("QH_WINDOW_KERNEL", kernel)
+        h = qa.HashWithQuality(1 << 28, 2 * k, bits, min_qual=38)
+        h.set_mode("partition")
+        h.enable_timing(True)
+        h.add_fastq(fq)
+        st = h.done()
+        m, v = sorted_pairs(*h.dump())
+        assert st["instances"] == n and st["distinct"] == om.size
+        assert (m == om).all() and (v == ov).all(), kernel
+        passes[kernel] = st["window_passes"]
+        assert_window_pass_is_live(h, "watched counters / " + kernel)
+        h.close()
+    assert passes == {"": 2, "noguard": 1}   # the hot window went round again, at the same table size
+
+
 def test_partitioned_growth_and_contention():
     """a 16384-slot table receiving far more distinct k-mers than it holds: windows overflow, the
     spill list is inserted directly, the table doubles; plus a poly-A read (one slot, 5000 updates)"""
