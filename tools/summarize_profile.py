@@ -4,6 +4,7 @@ profiles/pmc_traffic.json (HBM bytes per launch of the dominant kernel, for benc
 import collections, csv, glob, json, os, shutil, sys
 
 tag, name = sys.argv[1], sys.argv[2]
+workload = sys.argv[3] if len(sys.argv) > 3 else "c1"   # which whole-step figure of profiles/pmc_traffic.json this run supplies
 src = "gpurun_out/prof_%s" % tag
 dst = "profiles/%s" % name
 os.makedirs(dst, exist_ok=True)
@@ -45,21 +46,27 @@ for k, t in traffic.items():
 # HBM bytes of ONE step (bench.py's roofline.traffic): every kernel of the build, launches per step from the trace
 whole = None
 if "k_index_text" in out and "FETCH_SIZE" in out["k_index_text"]:
-    steps = out["k_index_text"]["FETCH_SIZE"]["launches"]
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 4   # tools/profile_bench.sh runs --steps 3 --warmup 1
     whole = 0.0
     for k, t in traffic.items():
         n = k.replace("void ", "")
         if n.startswith("k_") and not n.startswith(("k_random_access", "k_lds_rate")):
             whole += (t["fetch_bytes_x2"] + t["write_bytes"]) * out[k]["FETCH_SIZE"]["launches"] / steps
 if per:
-    old = {}
+    cur = {}
     if os.path.exists("profiles/pmc_traffic.json"):
-        old = json.load(open("profiles/pmc_traffic.json")).get("per_kernel_hbm_bytes_per_launch", {})
-    old.update(per)
-    json.dump({"per_kernel_hbm_bytes_per_launch": old, "whole_step_hbm_bytes": whole,
-               "source": "%s/traffic.json (kernels absent from that run keep their earlier figure): (TCC FETCH_SIZE*2 + WRITE_SIZE) KiB "
-                         "per launch, separate --pmc passes, gfx950 FETCH_SIZE x2 correction (MI355X_MICROARCH.md HBM section)" % dst},
-              open("profiles/pmc_traffic.json", "w"), indent=1, sort_keys=True)
+        cur = json.load(open("profiles/pmc_traffic.json"))
+    key = "whole_step_hbm_bytes" if workload == "c1" else "whole_step_hbm_bytes_" + workload
+    cur[key] = whole
+    cur.setdefault("sources", {})[key] = dst + "/traffic.json"
+    if workload == "c1":
+        old = cur.get("per_kernel_hbm_bytes_per_launch", {})
+        old.update(per)
+        cur["per_kernel_hbm_bytes_per_launch"] = old
+    cur["source"] = ("(TCC FETCH_SIZE*2 + WRITE_SIZE) KiB per launch summed over the kernels of one bench step, separate --pmc passes, "
+                     "gfx950 FETCH_SIZE x2 correction (MI355X_MICROARCH.md HBM section); whole_step_hbm_bytes = configs[1], "
+                     "whole_step_hbm_bytes_c2 = configs[2] on one GPU; see `sources` for the run behind each")
+    json.dump(cur, open("profiles/pmc_traffic.json", "w"), indent=1, sort_keys=True)
 for k in sorted(stats, key=lambda k: -stats[k])[:8]:
     t = traffic.get(k, {})
     print("%-45s %9.1f us  fetch(x2) %8.1f MB  write %8.1f MB" % (k[:45], stats[k] / 1e3, t.get("fetch_bytes_x2", 0) / 1e6, t.get("write_bytes", 0) / 1e6))
