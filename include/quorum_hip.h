@@ -252,9 +252,10 @@ int qh_multi_finish(qh_multi* m, qh_build_stats* total);
 int qh_multi_write(qh_multi* m, const char* path, int argc, const char* const* argv);
 /* Content export of all shards (as qh_build_dump). */
 int qh_multi_dump(qh_multi* m, uint64_t* mers, uint64_t* vals, uint64_t cap, uint64_t* n);
-/* What the handle is doing: number of shards, 1 if the exchange runs over RCCL, chunks processed, parts that fell back to
- * the host parser, bucket overflows resolved by a retry. Any pointer may be NULL. */
-int qh_multi_info(const qh_multi* m, int* n_devices, int* uses_rccl, uint64_t* rounds, uint64_t* fallback_parts,
+/* What the handle is doing: number of shards, 1 if the exchange runs over RCCL, chunks processed, chunks that fell back
+ * to the host parser (the GPU indexer rejected one of their parts), bucket overflows resolved by a retry. Any pointer
+ * may be NULL. */
+int qh_multi_info(const qh_multi* m, int* n_devices, int* uses_rccl, uint64_t* rounds, uint64_t* fallback_chunks,
                   uint64_t* retries);
 
 /* -------------------------------------------------------------- query side */

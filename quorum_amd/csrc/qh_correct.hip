@@ -1221,7 +1221,9 @@ static int corrector_init(qh_corrector* c) {
       qh_launch_stats(c->P.table, og, c->d_meta, c->stream);
       QH_HIP(hipMemcpyAsync(c->h_meta, c->d_meta, sizeof(qh_meta), hipMemcpyDeviceToHost, c->stream));
       QH_HIP(hipStreamSynchronize(c->stream));
-      const double distinct = (double)c->h_meta->stat_distinct;
+      // every entry fills a slot, whatever its quality (low-quality-only mers are often the majority of a database
+      // built from raw reads): the copy is sized by the occupied slots
+      const double distinct = (double)c->h_meta->stat_occupied;
       int lsize = og.lsize;
       while (lsize < 40 && distinct > target * (double)(1ull << lsize)) ++lsize;
       size_t free_b = 0, total_b = 0;

@@ -1,4 +1,5 @@
 // qh_jflayout.cpp -- see qh_jflayout.h: the Jellyfish large_hash::array keys image as recalled (PARITY UNPINNED).
+#include <new>
 #include "qh_jflayout.h"
 #include "qh_dbfile.h"
 #include "qh_host.h"
@@ -92,9 +93,10 @@ bool qh_jf_check_geom(qh_jf_geom& g, std::string& err) {
   if (g.key_len <= g.lsize) { err = "jf layout: the table has more entries than there are keys (key_len <= log2 size)"; return false; }
   if ((int)g.columns.size() != g.key_len) { err = "jf layout: the matrix does not have key_len columns"; return false; }
   const uint64_t size = 1ull << g.lsize;
+  // (max_reprobe comes from a file header: checked before anything is sized by it)
+  if (g.max_reprobe && (uint64_t)g.max_reprobe * ((uint64_t)g.max_reprobe + 1) / 2 >= size) { err = "jf layout: reprobe offsets reach past the table"; return false; }
   g.reprobes.resize((size_t)g.max_reprobe + 1);
   for (uint64_t i = 0; i <= g.max_reprobe; ++i) g.reprobes[i] = i * (i + 1) / 2;
-  if (g.reprobes.back() >= size && g.max_reprobe) { err = "jf layout: reprobe offsets reach past the table"; return false; }
   g.reprobe_len = bitsize((uint64_t)g.max_reprobe + 1);
   g.entry_bits = 1 + g.key_len - g.lsize + g.reprobe_len;
   if (g.entry_bits > 64) { err = "jf layout: an entry of more than 64 bits (tiny table for this mer length)"; return false; }
@@ -278,8 +280,12 @@ extern "C" int qh_jf_write_file(const char* path, int k, int bits, uint64_t size
                                 const uint64_t* vals, uint64_t n, int argc, const char* const* argv) {
   if (!path || (n && (!mers || !vals))) return qh_fail(QH_EBADARG, "null argument");
   std::string err;
-  if (!qh_jf_write_pairs(path, k, bits, size, reprobe_limit, mers, vals, n, argc, argv, err))
-    return qh_fail(err == "Hash is full" ? QH_EFULL : err.find("output file") != std::string::npos ? QH_EIO : QH_EBADARG, "%s", err.c_str());
+  try {
+    if (!qh_jf_write_pairs(path, k, bits, size, reprobe_limit, mers, vals, n, argc, argv, err))
+      return qh_fail(err == "Hash is full" ? QH_EFULL : err.find("output file") != std::string::npos ? QH_EIO : QH_EBADARG, "%s", err.c_str());
+  } catch (const std::bad_alloc&) {  // no exception crosses the C ABI
+    return qh_fail(QH_ENOMEM, "out of host memory building the image for '%s'", path);
+  }
   return QH_OK;
 }
 
@@ -288,7 +294,11 @@ extern "C" int qh_jf_read_file(const char* path, int* k, int* bits, uint64_t* si
   if (!path || !n) return qh_fail(QH_EBADARG, "null argument");
   std::string err;
   std::vector<uint64_t> m, v;
-  if (!qh_jf_read_pairs(path, k, bits, size, m, v, err)) return qh_fail(QH_EFORMAT, "%s for file '%s'", err.c_str(), path);
+  try {
+    if (!qh_jf_read_pairs(path, k, bits, size, m, v, err)) return qh_fail(QH_EFORMAT, "%s for file '%s'", err.c_str(), path);
+  } catch (const std::bad_alloc&) {  // a header that asks for more than the host has
+    return qh_fail(QH_ENOMEM, "out of host memory reading '%s'", path);
+  }
   *n = m.size();
   if (m.size() > cap) return mers || vals ? qh_fail(QH_EBADARG, "buffer too small: %zu entries", m.size()) : QH_OK;
   if (mers) memcpy(mers, m.data(), m.size() * 8);

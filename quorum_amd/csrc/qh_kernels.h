@@ -23,6 +23,7 @@ struct qh_meta {
   uint64_t stat_distinct, stat_total;
   uint32_t win_failed;   // windows of the last pass that were left as they were (an item hit the reprobe limit)
   uint32_t win_hot;      // ... because a counter came near its width (k_window_count's GUARD): same table size again
+  uint64_t stat_occupied;  // k_stats: slots that hold an entry of either quality
 };
 
 enum { QH_FMT_LINES_MOD4 = 1, QH_FMT_NO_AT = 2, QH_FMT_NO_PLUS = 4, QH_FMT_LEN_MISMATCH = 8,

@@ -520,17 +520,21 @@ void qh_launch_best_alternatives_generic(const uint64_t* table, const qh_geom& g
 __global__ __launch_bounds__(QH_BLOCK) void k_stats(const uint64_t* __restrict__ table, const qh_geom g,
                                                     qh_meta* __restrict__ meta) {
   const uint64_t n = qh_table_slots(g);
-  unsigned long long d = 0, t = 0;
+  unsigned long long d = 0, t = 0, occ = 0;
   for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t s = table[idx];
     const uint64_t v = s ? qh_slot_val(g, s, idx) : 0;
+    occ += s != 0;
     if ((v & 1) && v >= 2) { d += 1; t += v >> 1; }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { d += __shfl_xor(d, o, 64); t += __shfl_xor(t, o, 64); }
-  if ((threadIdx.x & 63) == 0 && d) {
-    atomicAdd(reinterpret_cast<unsigned long long*>(&meta->stat_distinct), d);
-    atomicAdd(reinterpret_cast<unsigned long long*>(&meta->stat_total), t);
+  for (int o = 32; o > 0; o >>= 1) { d += __shfl_xor(d, o, 64); t += __shfl_xor(t, o, 64); occ += __shfl_xor(occ, o, 64); }
+  if ((threadIdx.x & 63) == 0 && occ) {
+    if (d) {
+      atomicAdd(reinterpret_cast<unsigned long long*>(&meta->stat_distinct), d);
+      atomicAdd(reinterpret_cast<unsigned long long*>(&meta->stat_total), t);
+    }
+    atomicAdd(reinterpret_cast<unsigned long long*>(&meta->stat_occupied), occ);  // (the table's load: the corrector sizes its copy by it)
   }
 }
 

@@ -65,10 +65,12 @@ class round_barrier {
   unsigned long gen = 0;
 public:
   explicit round_barrier(int n_) : n(n_) {}
-  void wait() {
+  // on_last runs in the last thread to arrive, before anyone is released: where the threads agree on what to do next
+  template <typename F>
+  void wait(F on_last) {
     std::unique_lock<std::mutex> lk(mu);
     const unsigned long g = gen;
-    if (++waiting == n) { waiting = 0; ++gen; cv.notify_all(); }
+    if (++waiting == n) { on_last(); waiting = 0; ++gen; cv.notify_all(); }
     else cv.wait(lk, [&] { return gen != g; });
   }
 };
@@ -311,9 +313,15 @@ extern "C" int qh_multi_add_fastq(qh_multi* m, const char* buf, size_t len, int 
   auto failed_any = [&]() { for (auto& s : m->sh) if (s.rc != QH_OK) return true; return false; };
   auto fail_here = [&](shard_dev& s, int rc) { s.rc = rc; s.err = qh_last_error(); };
 
+  // what every thread does next is decided once per phase, by the last thread to reach the barrier: a shard that failed
+  // (out of memory for its receive buffer, say) must keep ALL shards out of the grouped send / receive, or its peers
+  // would wait for it for ever
+  bool bad_extract = false, bad_alloc = false, bad_exchange = false, slow_all = false;
+
   auto worker = [&](int d) {
     shard_dev& s = m->sh[d];
     const size_t off = cut[d], plen = cut[d + 1] - cut[d];
+    const uint64_t records_before = s.hx->st.records;
     // ---- stage + extract by owner
     do {
       if (hipSetDevice(s.device) != hipSuccess) { qh_fail(QH_EHIP, "hipSetDevice(%d) failed", s.device); fail_here(s, QH_EHIP); break; }
@@ -347,16 +355,25 @@ extern "C" int qh_multi_add_fastq(qh_multi* m, const char* buf, size_t len, int 
       e = hipMemcpy(&m->counts[(size_t)d * n], s.d_counts, sizeof(uint64_t) * n, hipMemcpyDeviceToHost);
       if (e != hipSuccess) { qh_fail(QH_EHIP, "reading the bucket counts failed: %s", hipGetErrorString(e)); fail_here(s, QH_EHIP); }
     } while (0);
-    bar.wait();
-    bool slow = m->slow_mode;
-    for (int t = 0; t < n; ++t) slow |= need_fallback[t] != 0;   // the same answer in every thread
-    // ---- exchange: this shard's bucket from every device into one receive buffer
+    bar.wait([&] {
+      bad_extract = failed_any();
+      slow_all = m->slow_mode;
+      for (int t = 0; t < n; ++t) slow_all |= need_fallback[t] != 0;
+    });
+    const bool slow = slow_all;
+    // the text goes to the host parser on every shard: what the parts that did pass the GPU indexer counted is dropped
+    if (slow) s.hx->st.records = records_before;
+    // ---- receive buffer first, so that a shard that cannot have one is known before anybody sends
     uint64_t total = 0;
-    if (!failed_any() && !slow) {
+    if (!bad_extract && !slow) {
+      for (int t = 0; t < n; ++t) total += m->counts[(size_t)t * n + d];
+      int rc = dev_ensure((void**)&s.d_recv[slot], &s.recv_cap[slot], (total + 1) * 8, "receive buffer");
+      if (rc) fail_here(s, rc);
+    }
+    bar.wait([&] { bad_alloc = failed_any(); });
+    // ---- exchange: this shard's bucket from every device into its receive buffer
+    if (!bad_alloc && !slow) {
       do {
-        for (int t = 0; t < n; ++t) total += m->counts[(size_t)t * n + d];
-        int rc = dev_ensure((void**)&s.d_recv[slot], &s.recv_cap[slot], (total + 1) * 8, "receive buffer");
-        if (rc) { fail_here(s, rc); break; }
         // the insert of two rounds ago read this buffer: it completed before the previous round's insert was queued
         hipError_t e = hipSuccess;
         if (m->use_rccl) {
@@ -400,9 +417,9 @@ extern "C" int qh_multi_add_fastq(qh_multi* m, const char* buf, size_t len, int 
         if (e != hipSuccess) { qh_fail(QH_EHIP, "exchange into device %d failed: %s", s.device, hipGetErrorString(e)); fail_here(s, QH_EHIP); }
       } while (0);
     }
-    bar.wait();  // every bucket has been read: the next round may overwrite them
+    bar.wait([&] { bad_exchange = failed_any(); });  // every bucket has been read: the next round may overwrite them
     // ---- insert what arrived; returns once it is queued (it overlaps the next round's staging and extraction)
-    if (!failed_any()) {
+    if (!bad_exchange) {
       int rc;
       if (!slow) {
         rc = total ? qh_build_add_hashed_device(s.h, s.d_recv[slot], total) : qh_build_sync(s.h);

@@ -10,6 +10,7 @@
 #include <fcntl.h>
 #include <errno.h>
 #include <sys/stat.h>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -93,7 +94,13 @@ extern "C" int qh_query_open(qh_query** out, const char* path, int device) {
   qh_file_header fh;
   std::string err;
   if (!qh_header_read_file(path, fh, err)) return qh_fail(QH_EIO, "%s", err.c_str());
-  if (fh.format == "binary/quorum_db" && fh.layout == QH_LAYOUT_JF) return open_jf_layout(out, path, device);
+  if (fh.format == "binary/quorum_db" && fh.layout == QH_LAYOUT_JF) {
+    try {
+      return open_jf_layout(out, path, device);
+    } catch (const std::bad_alloc&) {  // no exception crosses the C ABI (a header may ask for more than the host has)
+      return qh_fail(QH_ENOMEM, "out of host memory reading '%s'", path);
+    }
+  }
   qh_geom g;
   if (!qh_geom_from_header(fh, g, err)) return qh_fail(QH_EFORMAT, "%s for file '%s'", err.c_str(), path);
   int fd = open(path, O_RDONLY);

@@ -39,7 +39,12 @@ def test_noalloc_matches_add_mers_device_twice():
         dev = torch.from_numpy(items.view(np.int64)).to("cuda:0")
         ref.add_mers_device(dev.data_ptr(), n)
         ref.sync()
+        # the property in the entry point's name: the driver's free-memory figure is the same before and after the
+        # call (hipMemGetInfo; any hipMalloc on the path, e.g. an overflow list, would lower it)
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info(0)[0]
         na.add_mers_device_noalloc(dev.data_ptr(), n)   # returns when the items are in the table
+        assert torch.cuda.mem_get_info(0)[0] == free_before
         rm, rv = sorted_pairs(*ref.dump())
         nm, nv = sorted_pairs(*na.dump())
         assert nm.size == rm.size and (nm == rm).all() and (nv == rv).all()
