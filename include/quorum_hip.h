@@ -209,6 +209,12 @@ int qh_mer_hash(int k, const uint64_t* mers, size_t n, uint64_t* hashes);
  * where the CLI cuts a stream into chunks for the GPU fast path. */
 size_t qh_fastq_4line_prefix(const char* buf, size_t len, int final_chunk);
 
+/* The n-1 cut points that divide a buffer of whole strict 4-line records (qh_fastq_4line_prefix) into n parts of about
+ * equal size, each beginning at a record start: cuts[0] = 0 <= cuts[1] <= ... <= cuts[n] = len. How the multi-GPU build
+ * shares a chunk among its GPUs and the corrector tool among its replicas. No upstream counterpart (upstream's threads
+ * take jobs of 100 reads from one parser, src/create_database.cc:52,61-66). Host-only. */
+int qh_fastq_split_records(const char* buf, size_t len, int n, size_t* cuts);
+
 /* Content export: every (mer, value) of this shard, unordered.  *n receives the
  * number of entries; at most cap are written (call with cap=0 to size). */
 int qh_build_dump(qh_build* h, uint64_t* mers, uint64_t* vals, uint64_t cap, uint64_t* n);

@@ -84,6 +84,7 @@ SIGNATURES = [
                                    C.POINTER(C.c_char_p)]),
     ("qh_jf_read_file", C.c_int, [C.c_char_p, _i32p, _i32p, _u64p, _u64p, _u64p, C.c_uint64, _u64p]),
     ("qh_fastq_4line_prefix", C.c_size_t, [C.c_char_p, C.c_size_t, C.c_int]),
+    ("qh_fastq_split_records", C.c_int, [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_size_t)]),
     ("qh_build_dump", C.c_int, [_p, _u64p, _u64p, C.c_uint64, _u64p]),
     ("qh_build_as_query", C.c_int, [_p, C.POINTER(_p)]),
     ("qh_build_extract_partitioned_device", C.c_int, [_p, _p, C.c_size_t, _p, C.c_uint64, _p]),

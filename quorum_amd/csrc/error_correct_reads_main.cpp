@@ -11,7 +11,9 @@
 // Differences from upstream: -t is accepted and ignored (the GPU supplies the parallelism; reads keep
 // their input order, as upstream with -t 1); --contaminant takes the FASTA file itself (upstream takes a
 // `jellyfish count -C` dump of it, Makefile.am:54-55); --gzip is refused (no zlib stream here);
-// --gpu N selects the HIP device.
+// --gpu N selects the HIP device; --devices a,b,... runs one replica of the corrector per listed device (the database
+// loaded on each): reads are independent, so every chunk is cut at record boundaries into as many parts, the parts are
+// corrected side by side and their text is written in input order -- the same bytes as with one device.
 #include <errno.h>
 #include <fcntl.h>
 #include <limits.h>
@@ -54,6 +56,7 @@ static const char* kHelp =
     " -d, --no-discard                         Do not discard reads, output a single N (false)\n"
     " -v, --verbose                            Be verbose (false)\n"
     "     --gpu=int                            HIP device (0)\n"
+    "     --devices=list                       HIP devices a,b,...: one replica of the corrector on each\n"
     " -U, --usage                              Usage\n"
     " -h, --help                               This message\n"
     " -V, --version                            Version";
@@ -102,6 +105,7 @@ struct args_t {
   uint32_t qual_cutoff_value = 0; bool qual_cutoff_value_given = false;
   std::string qual_cutoff_char; bool qual_cutoff_char_given = false;
   int gpu = 0;
+  std::vector<int> devices;
   const char* db = nullptr;
   std::vector<const char*> sequence;
 };
@@ -115,7 +119,7 @@ static void parse(int argc, char** argv, args_t& a) {
       {1, "contaminant", true}, {2, "trim-contaminant", false}, {3, "homo-trim", true}, {4, "gzip", false},
       {'M', "no-mmap", false}, {5, "apriori-error-rate", true}, {6, "poisson-threshold", true},
       {'p', "cutoff", true}, {'q', "qual-cutoff-value", true}, {'Q', "qual-cutoff-char", true},
-      {'d', "no-discard", false}, {'v', "verbose", false}, {7, "gpu", true}};
+      {'d', "no-discard", false}, {'v', "verbose", false}, {7, "gpu", true}, {8, "devices", true}};
   std::vector<const char*> pos;
   bool only_pos = false;
   for (int i = 1; i < argc; ++i) {
@@ -135,7 +139,7 @@ static void parse(int argc, char** argv, args_t& a) {
       val = eq ? eq + 1 : nullptr;
       if (!o->has_arg && val) error(std::string("option '--") + o->l + "' doesn't allow an argument");
     } else {
-      for (auto& x : opts) if (s[1] == x.s && x.s > 7) o = &x;
+      for (auto& x : opts) if (s[1] == x.s && x.s > 8) o = &x;
       if (!o) error(std::string("invalid option -- '") + s[1] + "'");
       if (o->has_arg) val = s[2] ? s + 2 : nullptr;
       else if (s[2]) error(std::string("invalid option -- '") + s[2] + "'");
@@ -166,6 +170,15 @@ static void parse(int argc, char** argv, args_t& a) {
       case 'd': a.no_discard = true; break;
       case 'v': a.verbose = true; break;
       case 7: a.gpu = (int)conv_u32(val); break;
+      case 8: {
+        a.devices.clear();
+        std::string item;
+        for (const char* c = val;; ++c) {
+          if (*c == ',' || *c == 0) { a.devices.push_back((int)conv_u32(item.c_str())); item.clear(); if (!*c) break; }
+          else item += *c;
+        }
+        break;
+      }
     }
   }
   if (a.qual_cutoff_value_given && a.qual_cutoff_char_given)
@@ -239,17 +252,22 @@ int main(int argc, char* argv[]) {
   auto secs = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
   auto vlog = [&](const std::string& m) { if (args.verbose) fprintf(stderr, "[%.3f] %s\n", secs(), m.c_str()); };
 
+  if (args.devices.empty()) args.devices.push_back(args.gpu);
+  const int nrep = (int)args.devices.size();
+  struct replica { qh_query* db = nullptr; qh_query* contaminant = nullptr; qh_corrector* ec = nullptr; };
+  std::vector<replica> rep((size_t)nrep);
   vlog("Loading mer database");  // :688-690
-  qh_query* db = nullptr;
-  if (qh_query_open(&db, args.db, args.gpu) != QH_OK) die(qh_last_error());
+  for (int r = 0; r < nrep; ++r)
+    if (qh_query_open(&rep[r].db, args.db, args.devices[r]) != QH_OK) die(qh_last_error());
+  qh_query* db = rep[0].db;
   int k = 0, bits = 0;
   uint64_t size = 0;
   qh_query_info(db, &k, &bits, &size);
 
-  qh_query* contaminant = nullptr;  // :692-708
-  if (args.contaminant) {
+  if (args.contaminant) {  // :692-708
     vlog("Loading contaminant sequences");
-    if (qh_contaminant_open_fasta(&contaminant, args.contaminant, k, args.gpu) != QH_OK) die(qh_last_error());
+    for (int r = 0; r < nrep; ++r)
+      if (qh_contaminant_open_fasta(&rep[r].contaminant, args.contaminant, k, args.devices[r]) != QH_OK) die(qh_last_error());
   }
 
   unsigned cutoff = args.cutoff;  // :712-718
@@ -282,8 +300,9 @@ int main(int argc, char* argv[]) {
     }
     if (!known || in_bytes / 64 < size) setenv("QH_EC_TABLE_LOAD", "0", 1);
   }
-  qh_corrector* ec = nullptr;
-  if (qh_corrector_create(&ec, db, contaminant, &p) != QH_OK) die(qh_last_error());
+  for (int r = 0; r < nrep; ++r)
+    if (qh_corrector_create(&rep[r].ec, rep[r].db, rep[r].contaminant, &p) != QH_OK) die(qh_last_error());
+  qh_corrector* ec = rep[0].ec;
 
   // open_file (:134-155): <prefix>.log / <prefix>.fa, or stderr / stdout without a prefix
   const std::string prefix = args.output_given ? args.output : "";
@@ -313,25 +332,70 @@ int main(int argc, char* argv[]) {
   // (appending through a shared mapping filled by eight threads, which pays for the database file, was measured here
   // and gains nothing over write(): the pieces are 150 MB and the loop already hides most of the write)
   // one chunk through the corrector; its text goes to the writer thread. Returns the bytes that formed whole records.
-  auto process = [&](const char* chunk, size_t have, bool eof) -> size_t {
-    size_t used = 0;
-    const double t1 = secs();
-    if (qh_corrector_correct_fastq(ec, chunk, have, eof, &used) != QH_OK) die(qh_last_error());
-    const char *fa, *lg;
-    size_t nfa, nlg;
-    qh_correct_stats st;
-    if (qh_corrector_fetch(ec, &fa, &nfa, &lg, &nlg, &st) != QH_OK) die(qh_last_error());
-    const double t2 = secs();
-    join_writer();  // chunk i-1 is out: its buffers are the ones the next fetch reuses
-    writer = std::thread([=, &fa_name, &log_name]() {
-      write_all(fa_fd, fa, nfa, fa_name);
-      write_all(log_fd, lg, nlg, log_name);
-    });
-    t_correct += t2 - t1;
-    t_write += secs() - t2;
+  struct piece { const char* fa; size_t nfa; const char* lg; size_t nlg; };
+  auto add_stats = [&](const qh_correct_stats& st) {
     total.reads += st.reads; total.corrected += st.corrected; total.skipped += st.skipped;
     total.substitutions += st.substitutions; total.truncations += st.truncations;
     total.bases_in += st.bases_in; total.bases_out += st.bases_out;
+  };
+  auto process = [&](const char* chunk, size_t have, bool eof) -> size_t {
+    size_t used = 0;
+    const double t1 = secs();
+    std::vector<piece> out;
+    // Replicas: the chunk's whole 4-line records, cut into one part per device at record boundaries; every part is
+    // corrected by its replica and the texts follow one another in input order. Text the cut cannot be trusted on
+    // (not strict 4-line records) goes to the first replica whole, like with one device.
+    bool split_done = false;
+    if (nrep > 1) {
+      const size_t whole = qh_fastq_4line_prefix(chunk, have, eof);
+      std::vector<size_t> cut((size_t)nrep + 1, 0);
+      if (whole && qh_fastq_split_records(chunk, whole, nrep, cut.data()) == QH_OK) {
+        std::vector<piece> parts((size_t)nrep, piece{nullptr, 0, nullptr, 0});
+        std::vector<qh_correct_stats> sts((size_t)nrep);
+        std::vector<std::string> errs((size_t)nrep);
+        std::vector<char> ok((size_t)nrep, 1);
+        auto one = [&](int r) {
+          const size_t len = cut[r + 1] - cut[r];
+          memset(&sts[r], 0, sizeof sts[r]);
+          if (!len) return;
+          size_t u = 0;
+          if (qh_corrector_correct_fastq(rep[r].ec, chunk + cut[r], len, 1, &u) != QH_OK || u != len ||
+              qh_corrector_fetch(rep[r].ec, &parts[r].fa, &parts[r].nfa, &parts[r].lg, &parts[r].nlg, &sts[r]) != QH_OK) {
+            ok[r] = 0;
+            errs[r] = qh_last_error();
+          }
+        };
+        std::vector<std::thread> th;
+        for (int r = 1; r < nrep; ++r) th.emplace_back(one, r);
+        one(0);
+        for (auto& t : th) t.join();
+        bool all = true;
+        for (char c : ok) all = all && c;
+        if (all) {
+          for (int r = 0; r < nrep; ++r) { out.push_back(parts[r]); add_stats(sts[r]); }
+          used = whole;
+          split_done = true;
+        }
+      }
+    }
+    if (!split_done) {
+      if (qh_corrector_correct_fastq(ec, chunk, have, eof, &used) != QH_OK) die(qh_last_error());
+      piece pc;
+      qh_correct_stats st;
+      if (qh_corrector_fetch(ec, &pc.fa, &pc.nfa, &pc.lg, &pc.nlg, &st) != QH_OK) die(qh_last_error());
+      out.push_back(pc);
+      add_stats(st);
+    }
+    const double t2 = secs();
+    join_writer();  // chunk i-1 is out: its buffers are the ones the next fetch reuses
+    writer = std::thread([out, fa_fd, log_fd, &fa_name, &log_name]() {
+      for (const piece& pc : out) {
+        write_all(fa_fd, pc.fa, pc.nfa, fa_name);
+        write_all(log_fd, pc.lg, pc.nlg, log_name);
+      }
+    });
+    t_correct += t2 - t1;
+    t_write += secs() - t2;
     return used;
   };
   // The plain loop: read a chunk, correct it, carry the partial record at its end over. `have` bytes of the file are
@@ -457,8 +521,10 @@ int main(int argc, char* argv[]) {
   if (fa_fd > 2) close(fa_fd);
   if (log_fd > 2) close(log_fd);
   if (pinned) qh_host_free(buf); else free(buf);
-  qh_corrector_destroy(ec);
-  if (contaminant) qh_query_close(contaminant);
-  qh_query_close(db);
+  for (auto& r : rep) {
+    qh_corrector_destroy(r.ec);
+    if (r.contaminant) qh_query_close(r.contaminant);
+    qh_query_close(r.db);
+  }
   return 0;
 }

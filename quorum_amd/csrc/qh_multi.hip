@@ -285,6 +285,14 @@ static void split_records(const char* buf, size_t len, int n, std::vector<size_t
   for (int d = 1; d <= n; ++d) if (cut[d] < cut[d - 1]) cut[d] = cut[d - 1];
 }
 
+extern "C" int qh_fastq_split_records(const char* buf, size_t len, int n, size_t* cuts) {
+  if (!buf || !cuts || n < 1) return qh_fail(QH_EBADARG, "bad argument");
+  std::vector<size_t> cut;
+  split_records(buf, len, n, cut);
+  for (int d = 0; d <= n; ++d) cuts[d] = cut[d];
+  return QH_OK;
+}
+
 // One round over a host buffer of FASTQ text (pinned memory copies fastest). The leading whole groups of 4 lines go
 // through the GPU path; *consumed receives how many bytes were taken (a partial tail stays for the next call unless
 // final_chunk). If the GPU indexer rejects the text (multi-line records), nothing of the round is inserted and the

@@ -321,8 +321,13 @@ def test_corrector_piped_input_equals_file_input(tmp_path):
         rs = subprocess.run([ec, "-d", "-p", "4", dbf, "/dev/fd/0"], input=text, capture_output=True, timeout=300,
                             env=dict(env, QUORUM_HIP_NO_READ_AHEAD="1"))
         assert rs.returncode == 0 and rs.stdout == rf.stdout and rs.stderr == rf.stderr, name
+        # replicas (--devices a,b,...: here three on the one GPU): every chunk cut into parts at record boundaries, the
+        # parts corrected side by side, the text in input order -- the same bytes
+        rr = subprocess.run([ec, "-d", "-p", "4", "--devices", "0,0,0", dbf, str(tmp_path / "in.fastq")], capture_output=True,
+                            timeout=300, env=env)
+        assert rr.returncode == 0 and rr.stdout == rf.stdout and rr.stderr == rf.stderr, name
     cut = fq[:len(fq) - 57]
-    rp = subprocess.run([ec, "-d", "-p", "4", dbf, "/dev/fd/0"], input=cut, capture_output=True, timeout=300, env=env)
+    rp = subprocess.run([ec, "-d", "-p", "4", "--devices", "0,0", dbf, "/dev/fd/0"], input=cut, capture_output=True, timeout=300, env=env)
     (tmp_path / "in.fastq").write_bytes(cut)
     rf = subprocess.run([ec, "-d", "-p", "4", dbf, str(tmp_path / "in.fastq")], capture_output=True, timeout=300, env=env)
     assert rp.returncode != 0 and rf.returncode != 0 and rp.stderr[-200:] == rf.stderr[-200:]
