@@ -155,6 +155,10 @@ extern "C" int qh_build_create(qh_build** out, int k, int bits, uint64_t size, i
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return qh_fail(QH_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
   h->own_stream = h->stream;
+  e = hipStreamCreateWithFlags(&h->pstream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->prep_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_pmeta, sizeof(qh_meta));
+  if (e != hipSuccess) { int rc = qh_fail(QH_EHIP, "setting up the preparation stream failed: %s", hipGetErrorString(e)); qh_build_destroy(h); return rc; }
   { int src = scratch_resolve(device, &h->noalloc_scratch); if (src) { qh_build_destroy(h); return src; } }
   const size_t bytes = (size_t)8 << g.lsize;
   e = hipMalloc((void**)&h->table, bytes);
@@ -183,6 +187,10 @@ extern "C" void qh_build_destroy(qh_build* h) {
   if (!h) return;
   hipError_t e = hipSetDevice(h->device); (void)e;
   if (h->stream) { e = hipStreamSynchronize(h->stream); (void)e; }
+  if (h->pstream) { e = hipStreamSynchronize(h->pstream); (void)e; e = hipStreamDestroy(h->pstream); (void)e; }
+  if (h->prep_done) { e = hipEventDestroy(h->prep_done); (void)e; }
+  void* alts[] = {h->alt.recs, h->alt.tiles, h->alt.nlplane, h->alt.rbsums, h->alt.segdesc, h->alt.planes, h->d_pmeta};
+  for (void* p : alts) if (p) { e = hipFree(p); (void)e; }
   void* ptrs[] = {h->table, h->g.wvals, h->d_meta, h->d_chunk, h->d_recs, h->d_tiles, h->d_ovf[0], h->d_ovf[1], h->d_items, h->d_shard_counts, h->d_rbsums, h->d_segdesc, h->d_planes, h->d_nlplane,
                   h->d_bins[0], h->d_bins[1], h->d_bin_counts[0], h->d_bin_counts[1], h->d_wfail[0], h->d_wfail[1], h->d_bspill};
   for (void* p : ptrs) if (p) { e = hipFree(p); (void)e; }
@@ -481,6 +489,7 @@ struct part_source {
   const uint8_t* fastq = nullptr;    // FASTQ chunk whose record table is in h->d_recs
   size_t fastq_len = 0;              // bytes of that chunk
   bool planes_ready = false;         // the text planes were made by the indexing pass
+  bool prepped = false;              // ... and the segment descriptors too, ahead of time (the bucket counters are cleared here)
   size_t rec_cap = 0;
   size_t max_bases = 0;              // upper bound of the chunk's bases
   const uint64_t* items = nullptr;   // or an item list
@@ -589,7 +598,7 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
     if ((rc = ensure((void**)&h->d_bins[0], &h->bins_cap[0], ((size_t)cap1 << b1) * 8, "level-1 buckets"))) return rc;
     if ((rc = ensure((void**)&h->d_bin_counts[0], &h->bin_counts_cap[0], l1c_bytes, "level-1 bucket counts"))) return rc;
   }
-  if (!src.fastq) {
+  if (!src.fastq || src.prepped) {
     if (open_new) QH_HIP(hipMemsetAsync(h->d_bin_counts[1], 0, wc_bytes, h->stream));
     if (b2) QH_HIP(hipMemsetAsync(h->d_bin_counts[0], 0, l1c_bytes, h->stream));
   }
@@ -611,11 +620,13 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
   if (src.fastq) {
     qh_fastq_aux aux;
     if ((rc = fastq_aux(h, src.fastq_len, src.rec_cap, src.max_bases, &aux))) return rc;
-    timing_begin(h, 0);
-    if (!src.planes_ready) qh_launch_text_planes(src.fastq, src.fastq_len, g, aux, h->stream);
-    qh_launch_segments(h->d_recs, (uint32_t)src.rec_cap, h->d_meta, g, aux, open_new ? h->d_bin_counts[1] : nullptr,
-                       open_new ? wc_bytes : 0, b2 ? h->d_bin_counts[0] : nullptr, l1c_bytes, h->stream);
-    timing_end(h, 0);
+    if (!src.prepped) {
+      timing_begin(h, 0);
+      if (!src.planes_ready) qh_launch_text_planes(src.fastq, src.fastq_len, g, aux, h->stream);
+      qh_launch_segments(h->d_recs, (uint32_t)src.rec_cap, h->d_meta, g, aux, open_new ? h->d_bin_counts[1] : nullptr,
+                         open_new ? wc_bytes : 0, b2 ? h->d_bin_counts[0] : nullptr, l1c_bytes, h->stream);
+      timing_end(h, 0);
+    }
     timing_begin(h, 1);
     qh_launch_partition_fastq(aux, (uint32_t)src.rec_cap, h->d_meta, g, l1_dst, check_owner, h->stream);
   } else {
@@ -648,23 +659,60 @@ extern "C" int qh_build_add_fastq_device(qh_build* h, const void* dev_buf, size_
   if (!dev_buf || ((uintptr_t)dev_buf & 15)) return qh_fail(QH_EBADARG, "device chunk must be non-null and 16-byte aligned");
   if (len > kMaxChunk) return qh_fail(QH_EBADARG, "chunk larger than %zu bytes", kMaxChunk);
   const size_t est = est_fastq_items(h, len);
-  int rc = begin_chunk(h, len / 2, est);
-  if (rc) return rc;
   const size_t ntiles = (len + QH_TILE_BYTES - 1) / QH_TILE_BYTES;
   const size_t rec_cap = len / 16 + 16;
-  if ((rc = ensure((void**)&h->d_tiles, &h->tile_cap, (ntiles + 1) * 4, "tile counts"))) return rc;
-  if ((rc = ensure((void**)&h->d_recs, &h->rec_cap, rec_cap * 16, "record table"))) return rc;
-  if ((rc = ensure((void**)&h->d_nlplane, &h->nlplane_cap, (len / 16 + 2) * 8 + 8192, "newline lists"))) return rc;
+  int rc;
+  // Early preparation: while the previous chunk's split kernels still run on the handle's stream, this chunk's index
+  // and segment kernels -- which need nothing of it -- fill the other set of per-chunk arrays on a stream of their
+  // own; the host then collects the previous chunk as ever. Only when the handle runs on its own stream: a caller's
+  // stream (qh_build_set_stream) orders the chunk's text behind whatever the caller enqueued there, which a second
+  // stream would not see.
+  const char* no_early = getenv("QH_NO_EARLY_PREP");  // (read per call: the tests switch it)
+  const bool early = h->pending && h->last_partitioned && h->stream == h->own_stream && !h->failed && !no_early &&
+                     use_partition(h, len / 2);
+  if (early) {
+    QH_HIP(hipSetDevice(h->device));
+    std::swap(h->d_recs, h->alt.recs); std::swap(h->rec_cap, h->alt.rec_cap);
+    std::swap(h->d_tiles, h->alt.tiles); std::swap(h->tile_cap, h->alt.tile_cap);
+    std::swap(h->d_nlplane, h->alt.nlplane); std::swap(h->nlplane_cap, h->alt.nlplane_cap);
+    std::swap(h->d_rbsums, h->alt.rbsums); std::swap(h->rbsums_cap, h->alt.rbsums_cap);
+    std::swap(h->d_segdesc, h->alt.segdesc); std::swap(h->segdesc_cap, h->alt.segdesc_cap);
+    std::swap(h->d_planes, h->alt.planes); std::swap(h->planes_cap, h->alt.planes_cap);
+    qh_fastq_aux aux;
+    if ((rc = ensure((void**)&h->d_tiles, &h->tile_cap, (ntiles + 1) * 4, "tile counts"))) return rc;
+    if ((rc = ensure((void**)&h->d_recs, &h->rec_cap, rec_cap * 16, "record table"))) return rc;
+    if ((rc = ensure((void**)&h->d_nlplane, &h->nlplane_cap, (len / 16 + 2) * 8 + 8192, "newline lists"))) return rc;
+    if ((rc = fastq_aux(h, len, rec_cap, len / 2, &aux))) return rc;
+    QH_HIP(hipMemsetAsync(h->d_pmeta, 0, sizeof(qh_meta), h->pstream));
+    // (not timed: the event pair of qh_build_kernel_time(0) still belongs to the chunk in flight)
+    qh_launch_index_fastq((const uint8_t*)dev_buf, len, h->d_tiles, h->d_nlplane, h->d_recs, (uint32_t)rec_cap, h->d_pmeta,
+                          &aux, h->g.min_qual, h->pstream);
+    qh_launch_segments(h->d_recs, (uint32_t)rec_cap, h->d_pmeta, h->g, aux, nullptr, 0, nullptr, 0, h->pstream);
+    QH_HIP(hipGetLastError());
+    QH_HIP(hipEventRecord(h->prep_done, h->pstream));
+    rc = begin_chunk(h, len / 2, est);  // collects the previous chunk
+    if (rc) { hipError_t e = hipStreamSynchronize(h->pstream); (void)e; return rc; }
+    QH_HIP(hipStreamWaitEvent(h->stream, h->prep_done, 0));
+    // lines, records and the format verdict: the first four words of the preparation's counters
+    QH_HIP(hipMemcpyAsync(h->d_meta, h->d_pmeta, 16, hipMemcpyDeviceToDevice, h->stream));
+  } else {
+    if ((rc = begin_chunk(h, len / 2, est))) return rc;
+    if ((rc = ensure((void**)&h->d_tiles, &h->tile_cap, (ntiles + 1) * 4, "tile counts"))) return rc;
+    if ((rc = ensure((void**)&h->d_recs, &h->rec_cap, rec_cap * 16, "record table"))) return rc;
+    if ((rc = ensure((void**)&h->d_nlplane, &h->nlplane_cap, (len / 16 + 2) * 8 + 8192, "newline lists"))) return rc;
+  }
   const bool part = use_partition(h, len / 2);
   qh_fastq_aux aux;
   if (part && (rc = fastq_aux(h, len, rec_cap, len / 2, &aux))) return rc;
   // one pass over the text: newline plane for the record table and, for the partitioned build, the text planes
-  qh_launch_index_fastq((const uint8_t*)dev_buf, len, h->d_tiles, h->d_nlplane, h->d_recs, (uint32_t)rec_cap, h->d_meta,
-                        part ? &aux : nullptr, h->g.min_qual, h->stream);
+  if (!early)
+    qh_launch_index_fastq((const uint8_t*)dev_buf, len, h->d_tiles, h->d_nlplane, h->d_recs, (uint32_t)rec_cap, h->d_meta,
+                          part ? &aux : nullptr, h->g.min_qual, h->stream);
   if (part) {
     part_source src;
     src.fastq = (const uint8_t*)dev_buf;
     src.planes_ready = true;
+    src.prepped = early;
     src.fastq_len = len;
     src.rec_cap = rec_cap;
     src.max_bases = len / 2;
@@ -680,6 +728,7 @@ extern "C" int qh_build_add_fastq_device(qh_build* h, const void* dev_buf, size_
   QH_HIP(hipGetLastError());
   h->pending = true;
   h->pending_fastq_len = len;
+  h->last_partitioned = part;
   return QH_OK;
 }
 

@@ -28,6 +28,21 @@ struct qh_build {
   uint64_t* d_planes = nullptr;    size_t planes_cap = 0;   // bit planes of the chunk
   uint64_t* d_bins[2] = {nullptr, nullptr}; size_t bins_cap[2] = {0, 0};       // level-1 / window buckets (bytes)
   unsigned long long* d_bin_counts[2] = {nullptr, nullptr}; size_t bin_counts_cap[2] = {0, 0};
+  // The other set of the per-chunk FASTQ arrays above (record table, tile counts, newline lists, segment sums and
+  // descriptors, text planes): while a partitioned chunk's split kernels still run, the NEXT chunk's index and segment
+  // kernels fill this set on a stream of their own (qh_build_add_fastq_device), then the two sets change places
+  struct prep_set {
+    uint4* recs = nullptr; size_t rec_cap = 0;
+    uint32_t* tiles = nullptr; size_t tile_cap = 0;
+    ushort4* nlplane = nullptr; size_t nlplane_cap = 0;
+    uint32_t* rbsums = nullptr; size_t rbsums_cap = 0;
+    uint2* segdesc = nullptr; size_t segdesc_cap = 0;
+    uint64_t* planes = nullptr; size_t planes_cap = 0;
+  } alt;
+  hipStream_t pstream = nullptr;     // stream of the early preparation
+  hipEvent_t prep_done = nullptr;
+  qh_meta* d_pmeta = nullptr;        // its own counters (lines, records, format verdict), copied into d_meta afterwards
+  bool last_partitioned = false;     // the chunk in flight went through the partitioned build
   bool zero_pending = false;  // qh_build_reset left the clearing of the table to the next partitioned chunk
   bool table_dirty = false;   // the table holds entries (a window must be loaded before it is updated)
   int mode = 0;               // 0 auto, 1 direct global-CAS build, 2 radix-partitioned LDS build

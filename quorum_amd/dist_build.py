@@ -249,7 +249,7 @@ class ShardedBuilder:
     flush() drain the pipeline."""
 
     def __init__(self, k, bits, total_size, min_qual, rank, world, device, reprobe_limit=126, group=None,
-                 cap_factor=1.25, force_pipeline=False):
+                 cap_factor=1.25, force_pipeline=False, own_stream=False):
         from .mer_database import HashWithQuality
         self.cap_factor = cap_factor     # bucket capacity = mean share x this (tests lower it to force the retry)
         assert world & (world - 1) == 0, "number of shards must be a power of two"
@@ -268,7 +268,10 @@ class ShardedBuilder:
                                       reprobe_limit=reprobe_limit, shard_bits=self.shard_bits, shard_id=rank)
             self._ins_stream = torch.cuda.Stream(self.device)
             self.h.set_stream(self._ins_stream.cuda_stream)
-        else:
+        elif not own_stream:
+            # the chunks are torch tensors: on torch's stream their text is ordered behind whatever produced it.
+            # own_stream: the caller has synchronised (bench.py draws its reads before the timed region); the handle
+            # then keeps its own stream and may prepare chunk i+1 on a second one while chunk i is still being split
             self.h.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self._buckets = [None, None]     # send side, two pieces in flight
         self._counts = torch.zeros(world, dtype=torch.int64, device=self.device)
