@@ -62,6 +62,7 @@ typedef struct qh_build_stats {
   uint64_t grows;         /* number of 2x table doublings performed    */
   uint64_t foreign;       /* k-mers dropped because another shard owns them */
   uint64_t window_passes; /* passes over the table by the partitioned build (one per batch of chunks) */
+  uint64_t early_preps;   /* FASTQ chunks indexed and cut into segments while their predecessor was still being split */
 } qh_build_stats;
 
 const char* qh_last_error(void);

@@ -22,7 +22,7 @@ class QhRecord(C.Structure):
 
 class QhBuildStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
-                ("instances", "hq_instances", "distinct", "slots", "records", "grows", "foreign", "window_passes")]
+                ("instances", "hq_instances", "distinct", "slots", "records", "grows", "foreign", "window_passes", "early_preps")]
 
 
 class QhDbInfo(C.Structure):

@@ -196,6 +196,7 @@ extern "C" void qh_build_destroy(qh_build* h) {
   for (void* p : ptrs) if (p) { e = hipFree(p); (void)e; }
   if (h->h_meta) { e = hipHostFree(h->h_meta); (void)e; }
   for (auto& pr : h->evk) for (hipEvent_t ev : pr) if (ev) { e = hipEventDestroy(ev); (void)e; }
+  for (hipEvent_t ev : h->evp) if (ev) { e = hipEventDestroy(ev); (void)e; }
   if (h->own_stream) { e = hipStreamDestroy(h->own_stream); (void)e; }
   delete h;
 }
@@ -315,6 +316,15 @@ static int launch_flush(qh_build* h, bool same_epoch);
 
 // Collects the chunk in flight (counters, deferred errors, growth). flush: the public meaning of qh_build_sync --
 // everything fed so far is in the table; without it a batch of deferred chunks stays open (begin_chunk).
+// the segment kernels of the last early preparation (they ended before the chunk they belong to began)
+static void fold_prep_timing(qh_build* h) {
+  if (!h->evp_pending) return;
+  if (hipEventQuery(h->evp[1]) != hipSuccess) { (void)hipGetLastError(); return; }  // of the chunk being handed over right now: next time
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, h->evp[0], h->evp[1]) == hipSuccess) { h->kernel_ms[0] += ms; h->kernel_launches[0] += 1; }
+  h->evp_pending = false;
+}
+
 static int sync_impl(qh_build* h, bool flush) {
   if (!h) return qh_fail(QH_EBADARG, "null handle");
   if (h->failed) return qh_fail(h->failed, "%s", h->failed_msg.c_str());
@@ -331,6 +341,7 @@ static int sync_impl(qh_build* h, bool flush) {
       if (hipEventElapsedTime(&ms, h->evk[i][0], h->evk[i][1]) == hipSuccess) { h->kernel_ms[i] += ms; h->kernel_launches[i] += 1; }
       h->evk_pending[i] = false;
     }
+    fold_prep_timing(h);
     const qh_meta m = *h->h_meta;
     const bool was_deferred = h->pending_deferred;
     const size_t flen = h->pending_fastq_len;
@@ -396,9 +407,12 @@ extern "C" int qh_build_enable_timing(qh_build* h, int on) {
   int rc = qh_build_sync(h);
   if (rc) return rc;
   QH_HIP(hipSetDevice(h->device));
-  if (on && !h->evk[0][0])
+  if (on && !h->evk[0][0]) {
     for (auto& pr : h->evk) for (hipEvent_t& ev : pr) QH_HIP(hipEventCreate(&ev));
+    for (hipEvent_t& ev : h->evp) QH_HIP(hipEventCreate(&ev));
+  }
   h->timing = on != 0;
+  h->evp_pending = false;
   for (int i = 0; i < 4; ++i) { h->kernel_ms[i] = 0; h->kernel_launches[i] = 0; h->evk_pending[i] = false; }
   return QH_OK;
 }
@@ -684,15 +698,21 @@ extern "C" int qh_build_add_fastq_device(qh_build* h, const void* dev_buf, size_
     if ((rc = ensure((void**)&h->d_nlplane, &h->nlplane_cap, (len / 16 + 2) * 8 + 8192, "newline lists"))) return rc;
     if ((rc = fastq_aux(h, len, rec_cap, len / 2, &aux))) return rc;
     QH_HIP(hipMemsetAsync(h->d_pmeta, 0, sizeof(qh_meta), h->pstream));
-    // (not timed: the event pair of qh_build_kernel_time(0) still belongs to the chunk in flight)
     qh_launch_index_fastq((const uint8_t*)dev_buf, len, h->d_tiles, h->d_nlplane, h->d_recs, (uint32_t)rec_cap, h->d_pmeta,
                           &aux, h->g.min_qual, h->pstream);
+    // timed with an event pair of its own (that of qh_build_kernel_time(0) belongs to the chunk in flight); the
+    // previous early preparation ended before that chunk began
+    fold_prep_timing(h);
+    const bool timed = h->timing && h->evp[0];
+    if (timed) { hipError_t e = hipEventRecord(h->evp[0], h->pstream); (void)e; }
     qh_launch_segments(h->d_recs, (uint32_t)rec_cap, h->d_pmeta, h->g, aux, nullptr, 0, nullptr, 0, h->pstream);
+    if (timed) { hipError_t e = hipEventRecord(h->evp[1], h->pstream); (void)e; h->evp_pending = true; }
     QH_HIP(hipGetLastError());
     QH_HIP(hipEventRecord(h->prep_done, h->pstream));
     rc = begin_chunk(h, len / 2, est);  // collects the previous chunk
     if (rc) { hipError_t e = hipStreamSynchronize(h->pstream); (void)e; return rc; }
     QH_HIP(hipStreamWaitEvent(h->stream, h->prep_done, 0));
+    h->st.early_preps += 1;
     // lines, records and the format verdict: the first four words of the preparation's counters
     QH_HIP(hipMemcpyAsync(h->d_meta, h->d_pmeta, 16, hipMemcpyDeviceToDevice, h->stream));
   } else {

@@ -72,6 +72,8 @@ struct qh_build {
   bool timing = false;
   hipEvent_t evk[4][2] = {};                 // per timed kernel: begin/end
   bool evk_pending[4] = {false, false, false, false};
+  hipEvent_t evp[2] = {};                    // the segment kernels of an early preparation (second stream): counted as kernel 0
+  bool evp_pending = false;
   double kernel_ms[4] = {0, 0, 0, 0};        // 0 direct/insert, 1 partition L1 (+extraction), 2 partition L2, 3 window build
   uint64_t kernel_launches[4] = {0, 0, 0, 0};
   void* noalloc_scratch = nullptr;  // this device's copy of qh_build.hip's file-scope scratch array

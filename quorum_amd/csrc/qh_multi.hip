@@ -464,7 +464,7 @@ extern "C" int qh_multi_finish(qh_multi* m, qh_build_stats* total) {
     if (rc) return rc;
     if ((rc = qh_build_get_stats(s.hx, &sx))) return rc;
     t.instances += st.instances; t.hq_instances += st.hq_instances; t.distinct += st.distinct;
-    t.slots += st.slots; t.grows += st.grows; t.window_passes += st.window_passes;
+    t.slots += st.slots; t.grows += st.grows; t.window_passes += st.window_passes; t.early_preps += st.early_preps;
     t.records += sx.records;   // counted where the reads were extracted
   }
   // reads that went through the host parser were parsed by every shard: count them once (shard 0's figure)
