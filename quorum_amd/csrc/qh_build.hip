@@ -157,6 +157,7 @@ extern "C" int qh_build_create(qh_build** out, int k, int bits, uint64_t size, i
   h->own_stream = h->stream;
   e = hipStreamCreateWithFlags(&h->pstream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->prep_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->main_mark, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_pmeta, sizeof(qh_meta));
   if (e != hipSuccess) { int rc = qh_fail(QH_EHIP, "setting up the preparation stream failed: %s", hipGetErrorString(e)); qh_build_destroy(h); return rc; }
   { int src = scratch_resolve(device, &h->noalloc_scratch); if (src) { qh_build_destroy(h); return src; } }
@@ -189,6 +190,7 @@ extern "C" void qh_build_destroy(qh_build* h) {
   if (h->stream) { e = hipStreamSynchronize(h->stream); (void)e; }
   if (h->pstream) { e = hipStreamSynchronize(h->pstream); (void)e; e = hipStreamDestroy(h->pstream); (void)e; }
   if (h->prep_done) { e = hipEventDestroy(h->prep_done); (void)e; }
+  if (h->main_mark) { e = hipEventDestroy(h->main_mark); (void)e; }
   void* alts[] = {h->alt.recs, h->alt.tiles, h->alt.nlplane, h->alt.rbsums, h->alt.segdesc, h->alt.planes, h->d_pmeta};
   for (void* p : alts) if (p) { e = hipFree(p); (void)e; }
   void* ptrs[] = {h->table, h->g.wvals, h->d_meta, h->d_chunk, h->d_recs, h->d_tiles, h->d_ovf[0], h->d_ovf[1], h->d_items, h->d_shard_counts, h->d_rbsums, h->d_segdesc, h->d_planes, h->d_nlplane,
@@ -196,7 +198,7 @@ extern "C" void qh_build_destroy(qh_build* h) {
   for (void* p : ptrs) if (p) { e = hipFree(p); (void)e; }
   if (h->h_meta) { e = hipHostFree(h->h_meta); (void)e; }
   for (auto& pr : h->evk) for (hipEvent_t ev : pr) if (ev) { e = hipEventDestroy(ev); (void)e; }
-  for (hipEvent_t ev : h->evp) if (ev) { e = hipEventDestroy(ev); (void)e; }
+  for (auto& pr : h->evp) for (hipEvent_t ev : pr) if (ev) { e = hipEventDestroy(ev); (void)e; }
   if (h->own_stream) { e = hipStreamDestroy(h->own_stream); (void)e; }
   delete h;
 }
@@ -316,13 +318,15 @@ static int launch_flush(qh_build* h, bool same_epoch);
 
 // Collects the chunk in flight (counters, deferred errors, growth). flush: the public meaning of qh_build_sync --
 // everything fed so far is in the table; without it a batch of deferred chunks stays open (begin_chunk).
-// the segment kernels of the last early preparation (they ended before the chunk they belong to began)
+// the segment kernels of early preparations that have ended (one may still run: that of the chunk being handed over)
 static void fold_prep_timing(qh_build* h) {
-  if (!h->evp_pending) return;
-  if (hipEventQuery(h->evp[1]) != hipSuccess) { (void)hipGetLastError(); return; }  // of the chunk being handed over right now: next time
-  float ms = 0;
-  if (hipEventElapsedTime(&ms, h->evp[0], h->evp[1]) == hipSuccess) { h->kernel_ms[0] += ms; h->kernel_launches[0] += 1; }
-  h->evp_pending = false;
+  for (int i = 0; i < 2; ++i) {
+    if (!h->evp_pending[i]) continue;
+    if (hipEventQuery(h->evp[i][1]) != hipSuccess) { (void)hipGetLastError(); continue; }
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, h->evp[i][0], h->evp[i][1]) == hipSuccess) { h->kernel_ms[0] += ms; h->kernel_launches[0] += 1; }
+    h->evp_pending[i] = false;
+  }
 }
 
 static int sync_impl(qh_build* h, bool flush) {
@@ -409,10 +413,10 @@ extern "C" int qh_build_enable_timing(qh_build* h, int on) {
   QH_HIP(hipSetDevice(h->device));
   if (on && !h->evk[0][0]) {
     for (auto& pr : h->evk) for (hipEvent_t& ev : pr) QH_HIP(hipEventCreate(&ev));
-    for (hipEvent_t& ev : h->evp) QH_HIP(hipEventCreate(&ev));
+    for (auto& pr : h->evp) for (hipEvent_t& ev : pr) QH_HIP(hipEventCreate(&ev));
   }
   h->timing = on != 0;
-  h->evp_pending = false;
+  h->evp_pending[0] = h->evp_pending[1] = false;
   for (int i = 0; i < 4; ++i) { h->kernel_ms[i] = 0; h->kernel_launches[i] = 0; h->evk_pending[i] = false; }
   return QH_OK;
 }
@@ -641,6 +645,9 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
                          open_new ? wc_bytes : 0, b2 ? h->d_bin_counts[0] : nullptr, l1c_bytes, h->stream);
       timing_end(h, 0);
     }
+    // the next chunk's early preparation starts here at the earliest: beside this chunk's own preparation (the first
+    // chunk of a run has one) both take as long as one after the other, and level 1 starts that much later
+    if (h->main_mark) QH_HIP(hipEventRecord(h->main_mark, h->stream));
     timing_begin(h, 1);
     qh_launch_partition_fastq(aux, (uint32_t)src.rec_cap, h->d_meta, g, l1_dst, check_owner, h->stream);
   } else {
@@ -697,16 +704,18 @@ extern "C" int qh_build_add_fastq_device(qh_build* h, const void* dev_buf, size_
     if ((rc = ensure((void**)&h->d_recs, &h->rec_cap, rec_cap * 16, "record table"))) return rc;
     if ((rc = ensure((void**)&h->d_nlplane, &h->nlplane_cap, (len / 16 + 2) * 8 + 8192, "newline lists"))) return rc;
     if ((rc = fastq_aux(h, len, rec_cap, len / 2, &aux))) return rc;
+    QH_HIP(hipStreamWaitEvent(h->pstream, h->main_mark, 0));
     QH_HIP(hipMemsetAsync(h->d_pmeta, 0, sizeof(qh_meta), h->pstream));
     qh_launch_index_fastq((const uint8_t*)dev_buf, len, h->d_tiles, h->d_nlplane, h->d_recs, (uint32_t)rec_cap, h->d_pmeta,
                           &aux, h->g.min_qual, h->pstream);
-    // timed with an event pair of its own (that of qh_build_kernel_time(0) belongs to the chunk in flight); the
-    // previous early preparation ended before that chunk began
+    // timed with event pairs of its own (that of qh_build_kernel_time(0) belongs to the chunk in flight), two in turn:
+    // the previous early preparation may still be running beside its predecessor's last kernel, the one before has ended
     fold_prep_timing(h);
-    const bool timed = h->timing && h->evp[0];
-    if (timed) { hipError_t e = hipEventRecord(h->evp[0], h->pstream); (void)e; }
+    const int ep = h->evp_cur ^= 1;
+    const bool timed = h->timing && h->evp[ep][0] && !h->evp_pending[ep];
+    if (timed) { hipError_t e = hipEventRecord(h->evp[ep][0], h->pstream); (void)e; }
     qh_launch_segments(h->d_recs, (uint32_t)rec_cap, h->d_pmeta, h->g, aux, nullptr, 0, nullptr, 0, h->pstream);
-    if (timed) { hipError_t e = hipEventRecord(h->evp[1], h->pstream); (void)e; h->evp_pending = true; }
+    if (timed) { hipError_t e = hipEventRecord(h->evp[ep][1], h->pstream); (void)e; h->evp_pending[ep] = true; }
     QH_HIP(hipGetLastError());
     QH_HIP(hipEventRecord(h->prep_done, h->pstream));
     rc = begin_chunk(h, len / 2, est);  // collects the previous chunk

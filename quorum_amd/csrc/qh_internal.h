@@ -41,6 +41,7 @@ struct qh_build {
   } alt;
   hipStream_t pstream = nullptr;     // stream of the early preparation
   hipEvent_t prep_done = nullptr;
+  hipEvent_t main_mark = nullptr;            // on the main stream: the point of the chunk in flight after which the next chunk's early preparation may start
   qh_meta* d_pmeta = nullptr;        // its own counters (lines, records, format verdict), copied into d_meta afterwards
   bool last_partitioned = false;     // the chunk in flight went through the partitioned build
   bool zero_pending = false;  // qh_build_reset left the clearing of the table to the next partitioned chunk
@@ -72,8 +73,9 @@ struct qh_build {
   bool timing = false;
   hipEvent_t evk[4][2] = {};                 // per timed kernel: begin/end
   bool evk_pending[4] = {false, false, false, false};
-  hipEvent_t evp[2] = {};                    // the segment kernels of an early preparation (second stream): counted as kernel 0
-  bool evp_pending = false;
+  hipEvent_t evp[2][2] = {};                 // the segment kernels of early preparations (second stream), two pairs in turn: counted as kernel 0
+  bool evp_pending[2] = {false, false};
+  int evp_cur = 0;
   double kernel_ms[4] = {0, 0, 0, 0};        // 0 direct/insert, 1 partition L1 (+extraction), 2 partition L2, 3 window build
   uint64_t kernel_launches[4] = {0, 0, 0, 0};
   void* noalloc_scratch = nullptr;  // this device's copy of qh_build.hip's file-scope scratch array
