@@ -125,9 +125,11 @@ def kernel_table(ktimes, st, steps, single, per_rank_step):
     partitioned = ktimes[3][1] > 0
     knames = ("segments(k_rec_segs_sum+k_scan_u32+k_rec_segs_apply)" if partitioned and single
               else "k_build_direct" if single else "k_insert_items",
-              "k_partition<0, false, 0>" if single else "k_partition<1, false, 0> (level 1)",
-              "k_partition<1, false, 0>" if single else "k_partition<1, false, 0> (level 2)",
-              "k_window_count<true>")  # the counting form with 16-bit counters at this geometry
+              # (the instantiations rocprofv3 lists for these geometries: k = 24, bin field in the low 32 bits;
+              #  the shard handle of the pipeline checks the owner of what it receives)
+              "k_partition<0, false, 0, 24, true>" if single else "k_partition<1, true, 0> (level 1)",
+              "k_partition<1, false, 0, 0, true>" if single else "k_partition<1, false, 0, 0, true> (level 2)",
+              "k_window_count<true, false>")  # the counting form with 16-bit counters at this geometry
     text_b = 2.0 * READ_LEN / KPR
     per_kernel = {}
     for i in range(4):
