@@ -73,10 +73,13 @@ __global__ __launch_bounds__(256) void k_rec_segs_sum(const uint4* __restrict__ 
   if (threadIdx.x == 0) tile_sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-// exclusive scan of n u32 values in place by one workgroup; the total goes to v[n]
-__global__ __launch_bounds__(1024) void k_scan_u32(uint32_t* __restrict__ v, uint32_t n) {
+// exclusive scan of the segment counts of n tiles of records in place by one workgroup; the total goes to v[n].
+// n comes from the record table's capacity (a record per 16 bytes of text); only the tiles that hold records are
+// scanned (the others hold zero and nobody reads their prefix): a twelfth of them for 100-base reads
+__global__ __launch_bounds__(1024) void k_scan_u32(uint32_t* __restrict__ v, uint32_t n, const qh_meta* __restrict__ meta) {
   __shared__ uint32_t part[1024];
-  const uint32_t total = block_scan_u32(v, n, part);
+  const uint32_t used = meta->format_err ? 0u : (meta->nrec + RB_TILE - 1) / RB_TILE;
+  const uint32_t total = block_scan_u32(v, used < n ? used : n, part);
   if (threadIdx.x == 1023) v[n] = total;
 }
 
@@ -166,7 +169,7 @@ void qh_launch_segments(const uint4* recs, uint32_t rec_cap, qh_meta* meta, cons
   hipLaunchKernelGGL(k_rec_segs_sum, dim3(ntiles), dim3(256), 0, s, recs, meta, a.tile_sums, (uint32_t)g.k,
                      static_cast<uint4*>(zero_a), (uint32_t)(zero_a_bytes / 16), static_cast<uint4*>(zero_b),
                      (uint32_t)(zero_b_bytes / 16));
-  hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, a.tile_sums, ntiles);
+  hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, a.tile_sums, ntiles, meta);
   hipLaunchKernelGGL(k_rec_segs_apply, dim3(ntiles), dim3(256), 0, s, recs, meta, a.tile_sums, (uint32_t)g.k, a.seg_desc);
 }
 
