@@ -118,7 +118,7 @@ def measure(b, pieces, piece_reads, steps, warmup, fence):
     return dt, [b.h.kernel_time(i) for i in range(4)], b.h.stats()
 
 
-def kernel_table(ktimes, st, steps, single, per_rank_step):
+def kernel_table(ktimes, st, steps, single, per_rank_step, shard_bits=0):
     """HIP-event averages of the main kernels (recorded on the stream they are launched on), each against the bytes
     IT must move per k-mer in this three-pass design"""
     avgs = [ms / n if n else 0.0 for ms, n in ktimes]
@@ -138,7 +138,9 @@ def kernel_table(ktimes, st, steps, single, per_rank_step):
         launches_per_step = ktimes[i][1] / steps
         per_launch = per_rank_step / max(launches_per_step, 1e-9)   # this rank's insertions per launch of the kernel
         e = {"avg_ms": avgs[i], "launches": int(ktimes[i][1]), "launches_per_step": launches_per_step}
-        own = (None, text_b + 8.0, 16.0, 8.0 + 8.0 * st["slots"] / max(1.0, per_launch))[i] if partitioned else None
+        # window buckets hold 4-byte items when remainder, position and quality bit fit (qh_items_pack_gsize)
+        item_b = 4.0 if 2 * K + 1 - (int(st["slots"]).bit_length() - 1) - shard_bits + 13 + 1 <= 32 else 8.0
+        own = (None, text_b + 8.0, 8.0 + item_b, item_b + 8.0 * st["slots"] / max(1.0, per_launch))[i] if partitioned else None
         if own:
             # level 1: the read's text in, one 8-byte item out; level 2: item in, item out; windows: item in, every
             # slot of the table written once per pass
@@ -151,9 +153,9 @@ def kernel_table(ktimes, st, steps, single, per_rank_step):
     return per_kernel, knames[dom], avgs[dom], int(ktimes[dom][1])
 
 
-def roofline_block(value_per_gpu, ktimes, st, steps, single, per_rank_step, traffic):
+def roofline_block(value_per_gpu, ktimes, st, steps, single, per_rank_step, traffic, shard_bits=0):
     achieved = value_per_gpu * ALG_BYTES_PER_KMER / 1e9
-    per_kernel, dom, dom_ms, dom_n = kernel_table(ktimes, st, steps, single, per_rank_step)
+    per_kernel, dom, dom_ms, dom_n = kernel_table(ktimes, st, steps, single, per_rank_step, shard_bits)
     # Headline roofline = the WHOLE STEP: SURVEY 8(d)'s 18.6 algorithmic bytes per k-mer (16 B of table traffic + the
     # read's text) over the step's wall time. No single kernel moves those bytes (level 1 never touches the table,
     # the window pass never sees the text), so pricing one kernel's time with them would flatter it.
@@ -354,7 +356,8 @@ def main():
                        "window_passes_per_step": int(st["window_passes"]),
                        "bucket_overflow_retries": int(getattr(b, "retries", 0)),
                        "exchange_rounds_max": int(getattr(b, "rounds_max", 0)), "parallelism": "hash-sharded x%d" % world},
-            "roofline": roofline_block(value / world, ktimes, st, args.steps, single, per_step / world, traffic),
+            "roofline": roofline_block(value / world, ktimes, st, args.steps, single, per_step / world, traffic,
+                                       shard_bits=world.bit_length() - 1),
         }
         if check is not None:
             out["content_check"] = check

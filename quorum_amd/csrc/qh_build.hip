@@ -289,7 +289,7 @@ static int resolve_full(qh_build* h, uint64_t n_ovf, uint32_t n_winfail, uint32_
       nw = 1u << (h->g.lsize - QH_WINDOW_BITS);
       if ((rc = ensure((void**)&h->d_wfail[wf ^ 1], &h->wfail_cap[wf ^ 1], (size_t)nw * 4, "window flags"))) return rc;
       qh_launch_window_redo(h->table, h->g, h->d_bins[1], h->defer_capw, h->d_bin_counts[1], h->defer_nw, nw,
-                            h->d_wfail[wf ^ 1], h->d_wfail[wf], n_prev, h->d_meta, h->stream);
+                            h->d_wfail[wf ^ 1], h->d_wfail[wf], n_prev, h->d_meta, h->stream, h->defer_pack);
       h->st.window_passes += 1;
     }
     QH_HIP(hipGetLastError());
@@ -547,7 +547,7 @@ static int launch_flush(qh_build* h, bool same_epoch) {
   }
   timing_begin(h, 3);
   qh_launch_window_build(h->table, h->g, h->d_bins[1], h->defer_capw, h->d_bin_counts[1], h->defer_nw,
-                         (h->table_dirty ? 1 : 0) | (h->zero_pending ? 2 : 0), h->d_wfail[0], h->d_meta, h->stream);
+                         (h->table_dirty ? 1 : 0) | (h->zero_pending ? 2 : 0), h->d_wfail[0], h->d_meta, h->stream, h->defer_pack);
   timing_end(h, 3);
   h->zero_pending = false;  // every window has been written
   // items that overflowed a bucket (the last chunk's, then the batch's list): plain global-CAS insertion
@@ -584,15 +584,19 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
   const bool open_new = !h->defer_open;
   bool batch = !open_new;
   size_t capw = h->defer_capw;
+  // packed window buckets where the geometry allows (half the bytes for level 2 to write and the window pass to read)
+  const bool no_pack = getenv("QH_NO_PACK") != nullptr;  // A/B runs and tests (read per chunk)
+  const int pack = open_new ? (no_pack ? 0 : qh_items_pack_gsize(g)) : h->defer_pack;
+  const size_t item_bytes = pack ? 4 : 8;
   if (open_new) {
     capw = max_items / nw + max_items / nw / 5 + 512;
     const size_t budget = defer_budget_bytes(h);
     if (budget) {
-      size_t per_w = budget / 8 / nw;
+      size_t per_w = budget / item_bytes / nw;
       const uint64_t limit = qh_window_count_cap_limit(g);  // the counting window kernel needs counters above a bucket
       if (limit && per_w > limit) per_w = (size_t)limit;
       const size_t need_one = est_items / nw + est_items / nw / 5 + 512;
-      if (per_w >= 2 * need_one && ensure((void**)&h->d_bins[1], &h->bins_cap[1], (size_t)nw * per_w * 8, "window buckets") == QH_OK) {
+      if (per_w >= 2 * need_one && ensure((void**)&h->d_bins[1], &h->bins_cap[1], (size_t)nw * per_w * item_bytes, "window buckets") == QH_OK) {
         // (with the buckets a list of a sixteenth of their capacity for what overflows single buckets)
         if (ensure((void**)&h->d_bspill, &h->bspill_cap, ((size_t)nw * per_w / 16 + 65536) * 8, "batch spill list") == QH_OK) {
           capw = per_w;
@@ -600,8 +604,9 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
         }
       }
     }
-    if (!batch && (rc = ensure((void**)&h->d_bins[1], &h->bins_cap[1], (size_t)nw * capw * 8, "window buckets"))) return rc;
+    if (!batch && (rc = ensure((void**)&h->d_bins[1], &h->bins_cap[1], (size_t)nw * capw * item_bytes, "window buckets"))) return rc;
     h->defer_capw = capw;
+    h->defer_pack = pack;
     h->defer_nw = nw;
     h->defer_items = 0;
     h->defer_cap_items = batch ? (uint64_t)nw * (capw - 512) / 6 * 5 : 0;  // windows differ: a fifth stays free
@@ -629,9 +634,9 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
   h->defer_spill_cap = spill_cap;
 
   qh_part_dst win_dst = {h->d_bins[1], capw, h->d_bin_counts[1], g.shard_bits + QH_WINDOW_BITS, b2 ? b2 : wid_bits,
-                         b2, spill, spill_cap, 1};
+                         b2, spill, spill_cap, 1, pack};
   qh_part_dst l1_dst = win_dst;
-  if (b2) l1_dst = {h->d_bins[0], cap1, h->d_bin_counts[0], g.shard_bits + QH_WINDOW_BITS + b2, b1, 0, spill, spill_cap, QH_COUNT_STRIDE};
+  if (b2) l1_dst = {h->d_bins[0], cap1, h->d_bin_counts[0], g.shard_bits + QH_WINDOW_BITS + b2, b1, 0, spill, spill_cap, QH_COUNT_STRIDE, 0};
   else win_dst.out_bin_shift = 0;
   const int check_owner = g.shard_bits > 0;
 
@@ -1082,7 +1087,7 @@ extern "C" int qh_build_extract_partitioned_device(qh_build* h, const void* dev_
                         &aux, h->g.min_qual, h->stream);
   qh_launch_segments(h->d_recs, (uint32_t)rec_cap, h->d_meta, h->g, aux, nullptr, 0, nullptr, 0, h->stream);
   // bucket = owner shard = low shard_bits of the hash; a bucket that overflows is an error here
-  qh_part_dst dst = {dev_out, cap_per_shard, (unsigned long long*)dev_counts, 0, h->g.shard_bits, 0, nullptr, 0, 1};
+  qh_part_dst dst = {dev_out, cap_per_shard, (unsigned long long*)dev_counts, 0, h->g.shard_bits, 0, nullptr, 0, 1, 0};
   timing_begin(h, 1);
   qh_launch_partition_fastq(aux, (uint32_t)rec_cap, h->d_meta, h->g, dst, 0, h->stream);
   timing_end(h, 1);

@@ -55,6 +55,7 @@ struct qh_build {
   size_t free_at_first_use = 0;  // free device memory when the first batch was sized (automatic budget)
   bool defer_open = false;       // the window buckets hold items that are not in the table yet
   size_t defer_capw = 0;         // capacity of a window bucket in the open batch
+  int defer_pack = 0;                        // > 0: the open batch's buckets hold packed 32-bit items made with this gsize (qh_part_dst::pack_gsize)
   uint32_t defer_nw = 0;         // windows of the table the batch was opened for
   uint64_t defer_items = 0;      // items of the batch's chunks collected so far
   uint64_t defer_cap_items = 0;  // items the batch takes before it is flushed

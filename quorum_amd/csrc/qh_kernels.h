@@ -74,8 +74,18 @@ struct qh_part_dst {
   // cache line serialise in one L2 channel (measured: 0.5 ms for 64 adjacent counters), so the
   // first level keeps them QH_COUNT_STRIDE words apart.
   uint32_t out_count_stride;
+  // > 0: the buckets hold PACKED items, 32 bits each: {remainder | position in the window : QH_WINDOW_BITS | quality : 1}
+  // -- what a window kernel needs of an item once the bucket names the window (qh_items_pack_gsize; the value is the
+  // table's lsize + shard_bits, the shift that yields the remainder). Items that do not fit a bucket are spilled whole.
+  int32_t pack_gsize;
 };
 #define QH_COUNT_STRIDE 513u
+// Window buckets can hold packed items when remainder, position and quality bit fit 32 bits (k = 24 from 2^30 slots on,
+// shorter mers earlier): returns the gsize to pack with, or 0. The buckets are the bulk of the partitioned build's
+// traffic at large tables: level 2 writes them, the window pass reads them.
+static inline int32_t qh_items_pack_gsize(const qh_geom& g) {
+  return g.rbits + QH_WINDOW_BITS + 1 <= 32 && g.lsize >= QH_WINDOW_BITS ? g.lsize + g.shard_bits : 0;
+}
 // Per-chunk device arrays of the FASTQ source (qh_partition.hip):
 //   tile_sums  ceil(rec_cap/1024) + 1 words     scan scratch; ends with the segment total
 //   seg_desc   max_segs x 8 B                    {first base offset, (distance to its quality) << 4 | k-mers}
@@ -103,12 +113,14 @@ void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsign
 // been cleared yet (windows without items must be zeroed here)
 // A window whose items do not all find a slot within the reprobe limit is left as it was: fail[w] = 1 (0 for every
 // other window) and meta->win_failed counts them; qh_launch_window_redo runs those buckets again on the grown table.
+// pack_gsize: 0 = 64-bit items, else the buckets hold packed items made with this gsize (qh_part_dst::pack_gsize; for
+// the redo it is the gsize the buckets were made with, not the grown table's)
 void qh_launch_window_build(uint64_t* table, const qh_geom& g, const uint64_t* items, uint64_t cap,
                             const unsigned long long* counts, uint32_t n_windows, int table_state, uint32_t* fail,
-                            qh_meta* meta, hipStream_t s);
+                            qh_meta* meta, hipStream_t s, int pack_gsize = 0);
 void qh_launch_window_redo(uint64_t* table, const qh_geom& g, const uint64_t* items, uint64_t cap,
                            const unsigned long long* counts, uint32_t n_buckets, uint32_t n_windows, uint32_t* fail,
-                           const uint32_t* prev_fail, uint32_t n_prev, qh_meta* meta, hipStream_t s);
+                           const uint32_t* prev_fail, uint32_t n_prev, qh_meta* meta, hipStream_t s, int pack_gsize = 0);
 
 // largest bucket capacity for which qh_launch_window_build still takes its fastest counting kernel at this geometry
 // (counters must stay above a bucket's fill); 0 = the capacity does not change the kernel

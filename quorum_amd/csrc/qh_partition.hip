@@ -202,6 +202,8 @@ struct qp_params {
   uint32_t in_count_stride;
   uint64_t in_n;
   int in_hashed;       // 0: (mer<<1|q) as the C ABI passes them, 1: (hash<<1|q)
+  int out_pack_gsize;  // > 0: the buckets take packed 32-bit items (qh_part_dst::pack_gsize)
+  int out_pack_sbits;  // ... the table's shard_bits
 };
 
 enum { QP_SRC_FASTQ = 0, QP_SRC_ITEMS = 1 };
@@ -437,11 +439,19 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
       const uint32_t b = bin_of_item(v);
       const uint64_t dst = (uint64_t)gbase[b] + (j - offs[b]);
       if (dst < p.out_cap) {
-        uint64_t* at = &p.out[(((uint64_t)in_bucket << p.out_bin_shift) | b) * p.out_cap + dst];
-        // level 1's buckets are read once, by level 2, after all of them are written: kept out of the caches
-        // (level 2 then runs 5 % faster; the same hint on level 2's own stores or on the item loads costs time)
-        if (SRC == QP_SRC_FASTQ) __builtin_nontemporal_store(v, at);
-        else *at = v;
+        const uint64_t oidx = (((uint64_t)in_bucket << p.out_bin_shift) | b) * p.out_cap + dst;
+        if (p.out_pack_gsize) {  // window buckets of a table whose remainder is short: 4 bytes per item
+          const uint64_t hh = v >> 1;
+          reinterpret_cast<uint32_t*>(p.out)[oidx] =
+              ((uint32_t)v & 1u) | (((uint32_t)(hh >> p.out_pack_sbits) & ((1u << QH_WINDOW_BITS) - 1u)) << 1) |
+              ((uint32_t)(hh >> p.out_pack_gsize) << (QH_WINDOW_BITS + 1));
+        } else {
+          uint64_t* at = &p.out[oidx];
+          // level 1's buckets are read once, by level 2, after all of them are written: kept out of the caches
+          // (level 2 then runs 5 % faster; the same hint on level 2's own stores or on the item loads costs time)
+          if (SRC == QP_SRC_FASTQ) __builtin_nontemporal_store(v, at);
+          else *at = v;
+        }
       }
       else qp_spill(p, v);
     }
@@ -464,12 +474,14 @@ static void fill_common(qp_params& p, const qh_part_dst& d, qh_meta* meta, int c
   p.bin_shift = d.bin_shift; p.bin_mask = (1u << d.bin_bits) - 1; p.bin_bits = (uint32_t)d.bin_bits; p.out_bin_shift = d.out_bin_shift;
   p.spill = d.spill; p.spill_cap = d.spill_cap; p.meta = meta;
   p.check_owner = check_owner; p.count_instances = count_instances;
+  p.out_pack_gsize = d.pack_gsize;
 }
 
 void qh_launch_partition_fastq(const qh_fastq_aux& a, uint32_t rec_cap, qh_meta* meta, const qh_geom& g,
                                const qh_part_dst& d, int check_owner, hipStream_t s) {
   qp_params p = {};
   fill_common(p, d, meta, check_owner, 1);
+  p.out_pack_sbits = g.shard_bits;
   p.planes = a.planes; p.plane_words = a.plane_words; p.seg_desc = a.seg_desc;
   p.seg_total = a.tile_sums + (rec_cap + RB_TILE - 1) / RB_TILE;
   const dim3 grid(256), block(QP_THREADS);
@@ -504,6 +516,7 @@ void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsign
                                const qh_part_dst& d, int check_owner, int count_instances, hipStream_t s) {
   qp_params p = {};
   fill_common(p, d, meta, check_owner, count_instances);
+  p.out_pack_sbits = g.shard_bits;
   p.in = in; p.in_cap = in_cap; p.in_counts = in_counts; p.in_count_stride = in_count_stride ? in_count_stride : 1; p.in_n = in_n; p.in_hashed = in_hashed;
   const uint64_t most = in_counts ? in_cap : in_n;
   uint64_t tiles = (most + QP_TILE_ITEMS - 1) / QP_TILE_ITEMS;
@@ -545,14 +558,27 @@ void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsign
 // set and meta->win_failed counts it; the bucket stays as it was. The host then doubles the table and runs the failed
 // windows' buckets again (FILTER: a window of the grown table takes, from the bucket of the window it descends from,
 // the items whose hash names it). Nothing is queued per item, so a batch of any size needs no overflow memory.
-template <bool NARROW, bool FILTER>
+// PACKED: the buckets hold 32-bit items {remainder | position | quality} (qh_part_dst::pack_gsize); the bucket number
+// is the window the items were sorted for, which gives back the bits cut out: what the kernels see is (hash << 1 | q)
+// as ever. pk_gsize is the gsize the buckets were made with (FILTER: the table has grown since).
+template <bool PACKED>
+__device__ __forceinline__ uint64_t qw_load(const uint64_t* __restrict__ items, uint64_t idx, uint32_t bkt, const qh_geom& g,
+                                            int pk_gsize) {
+  if (!PACKED) return items[idx];
+  const uint32_t n = reinterpret_cast<const uint32_t*>(items)[idx];
+  const uint64_t h = ((uint64_t)(n >> (QH_WINDOW_BITS + 1)) << pk_gsize) | ((uint64_t)bkt << (g.shard_bits + QH_WINDOW_BITS)) |
+                     ((uint64_t)((n >> 1) & ((1u << QH_WINDOW_BITS) - 1u)) << g.shard_bits) | (uint32_t)g.shard_id;
+  return (h << 1) | (n & 1u);
+}
+
+template <bool NARROW, bool FILTER, bool PACKED = false>
 __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restrict__ table, const qh_geom g,
                                                              const uint64_t* __restrict__ items, uint64_t cap,
                                                              const unsigned long long* __restrict__ counts,
                                                              int table_dirty, qh_meta* __restrict__ meta,
                                                              uint32_t* __restrict__ fail,
                                                              const uint32_t* __restrict__ prev_fail, uint32_t prev_mask,
-                                                             uint32_t bucket_mask, uint32_t win_mask) {
+                                                             uint32_t bucket_mask, uint32_t win_mask, int pk_gsize) {
   __shared__ uint64_t win[1u << QH_WINDOW_BITS];
   __shared__ uint64_t ring[QP_WAVES][QW_RING];  // window + rings = half of the CU's LDS: two workgroups per CU
   uint32_t* wnew = reinterpret_cast<uint32_t*>(&ring[0][0]);  // reused once the rings have drained
@@ -578,10 +604,10 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
   const uint32_t seg = (uint32_t)((n + QP_WAVES - 1) / QP_WAVES);
   const uint32_t s0 = (uint32_t)(((uint64_t)wave * seg) < n ? (uint64_t)wave * seg : n);
   const uint32_t seg_n = (uint32_t)((uint64_t)s0 + seg <= n ? seg : n - s0);
-  const uint64_t* src = items + (uint64_t)bkt * cap + s0;
+  const uint64_t sbase = (uint64_t)bkt * cap + s0;
   // first 64 items in flight while the window is brought into LDS; items [tail, tail + 64) are on request
   // whenever tail < seg_n
-  uint64_t pend = (uint32_t)lane < seg_n ? src[lane] : QP_NONE;
+  uint64_t pend = (uint32_t)lane < seg_n ? qw_load<PACKED>(items, sbase + lane, bkt, g, pk_gsize) : QP_NONE;
   bool lane_fail = false;
   uint4* tw = reinterpret_cast<uint4*>(table + ((uint64_t)w << QH_WINDOW_BITS));
   uint4* lw = reinterpret_cast<uint4*>(win);
@@ -616,7 +642,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
     if (avail < gate) {  // the ring runs low: queue the items that have arrived, request the next
       myring[(tail + lane) & (QW_RING - 1)] = pend;
       tail += seg_n - tail < 64 ? seg_n - tail : 64;
-      if (tail < seg_n) pend = tail + lane < seg_n ? src[tail + lane] : QP_NONE;
+      if (tail < seg_n) pend = tail + lane < seg_n ? qw_load<PACKED>(items, sbase + tail + lane, bkt, g, pk_gsize) : QP_NONE;
       else gate = 0;
       avail = tail - head;  // >= 64 unless the segment has ended
     }
@@ -760,13 +786,13 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
 // lane that sees it marks the window as failed-hot (fail[w] = 2) and the window is left as it was, like one that ran
 // out of probes; the host runs such windows again with the compare-and-swap kernel, at the same table size. A key
 // must be seen a thousand times in one bucket for that: the reads' own coverage never does it, repeats may.
-template <bool CB16, bool GUARD = false>
+template <bool CB16, bool GUARD = false, bool PACKED = false>
 __global__ __launch_bounds__(QP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_window_count(uint64_t* __restrict__ table, const qh_geom g,
                                                              const uint64_t* __restrict__ items, uint64_t cap,
                                                              const unsigned long long* __restrict__ counts,
                                                              uint32_t n_windows, int table_dirty,
                                                              qh_meta* __restrict__ meta, int cb_arg,
-                                                             uint32_t* __restrict__ fail, uint32_t hot_limit) {
+                                                             uint32_t* __restrict__ fail, uint32_t hot_limit, int pk_gsize) {
   typedef typename std::conditional<CB16, uint32_t, uint64_t>::type tag_t;  // tag = remainder | probe + 1
   __shared__ uint64_t win[1u << QH_WINDOW_BITS];
   __shared__ uint64_t ring[QP_WAVES][QW_RING];  // window + rings = half of the CU's LDS: two workgroups per CU
@@ -797,15 +823,20 @@ __global__ __launch_bounds__(QP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   // The workgroup walks windows blockIdx.x, + gridDim.x, ... (one workgroup per CU: the window fills its LDS), so
   // that what a fresh workgroup would wait for is requested a window ahead: the next bucket's size while this
   // window is counted, the first items of this wave's segment of it before this window is written out.
-  uint32_t seg_n = 0;             // this wave's segment of the bucket: src[0 .. seg_n)
-  const uint64_t* src = items;
-  uint64_t pend = QP_NONE;        // items [tail, tail + 64) of the segment, requested whenever tail < seg_n
+  uint32_t seg_n = 0;             // this wave's segment of the bucket: items [sbase, sbase + seg_n) of bucket sbkt
+  uint64_t sbase = 0;
+  // items [tail, tail + 64) of the segment, requested whenever tail < seg_n. PACKED: the 32-bit word as it lies in the
+  // bucket -- this kernel needs no more of an item than the word holds (the buckets were made for this table: pk_gsize is
+  // its gsize), so nothing is put together again
+  typedef typename std::conditional<PACKED, uint32_t, uint64_t>::type item_t;
+  const item_t* __restrict__ ibase = reinterpret_cast<const item_t*>(items);
+  item_t pend = (item_t)QP_NONE;
   auto open_bucket = [&](uint32_t w, uint64_t n) {
     const uint32_t seg = (uint32_t)((n + QP_WAVES - 1) / QP_WAVES);
     const uint32_t s0 = (uint32_t)(((uint64_t)wave * seg) < n ? (uint64_t)wave * seg : n);
     seg_n = (uint32_t)((uint64_t)s0 + seg <= n ? seg : n - s0);
-    src = items + (uint64_t)w * cap + s0;
-    pend = (uint32_t)lane < seg_n ? src[lane] : QP_NONE;
+    sbase = (uint64_t)w * cap + s0;
+    pend = (uint32_t)lane < seg_n ? ibase[sbase + lane] : (item_t)QP_NONE;
   };
   auto bucket_size = [&](uint32_t w) -> uint64_t {
     if (w >= n_windows) return 0;
@@ -859,14 +890,21 @@ __global__ __launch_bounds__(QP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
       if (avail < gate) {
         // decoded once, with every lane busy. 16-bit counters: {tag at probe 0 : 32 | log2(increment) << 16 | position};
         // wide tags: {tag at probe 0 : up to 50 | quality : 1 | position : QH_WINDOW_BITS}
-        const uint64_t h = pend >> 1;
-        const uint32_t p0 = (uint32_t)(h >> g.shard_bits) & wmask;
-        const uint64_t t0 = ((gsize >= 64 ? 0 : (h >> gsize)) << g.pbits) | 1u;
+        uint32_t p0;
+        uint64_t t0;
+        if (PACKED) {
+          p0 = ((uint32_t)pend >> 1) & wmask;
+          t0 = ((uint64_t)((uint32_t)pend >> (QH_WINDOW_BITS + 1)) << g.pbits) | 1u;
+        } else {
+          const uint64_t h = pend >> 1;
+          p0 = (uint32_t)(h >> g.shard_bits) & wmask;
+          t0 = ((gsize >= 64 ? 0 : (h >> gsize)) << g.pbits) | 1u;
+        }
         const uint32_t sh = (uint32_t)pend & 1u ? (uint32_t)cb : 0u;
         myring[(tail + lane) & (QW_RING - 1)] =
-            CB16 ? ((t0 << 32) | p0 | (sh << 16)) : ((t0 << (QH_WINDOW_BITS + 1)) | ((pend & 1u) << QH_WINDOW_BITS) | p0);
+            CB16 ? ((t0 << 32) | p0 | (sh << 16)) : ((t0 << (QH_WINDOW_BITS + 1)) | ((uint64_t)((uint32_t)pend & 1u) << QH_WINDOW_BITS) | p0);
         tail += seg_n - tail < 64 ? seg_n - tail : 64;
-        if (tail < seg_n) pend = tail + lane < seg_n ? src[tail + lane] : QP_NONE;
+        if (tail < seg_n) pend = tail + lane < seg_n ? ibase[sbase + tail + lane] : (item_t)QP_NONE;
         else gate = 0;
         avail = tail - head;  // >= 64 unless the segment has ended
       }
@@ -996,7 +1034,7 @@ uint64_t qh_window_count_cap_limit(const qh_geom& g) {
 
 void qh_launch_window_build(uint64_t* table, const qh_geom& g, const uint64_t* items, uint64_t cap,
                             const unsigned long long* counts, uint32_t n_windows, int table_dirty, uint32_t* fail,
-                            qh_meta* meta, hipStream_t s) {
+                            qh_meta* meta, hipStream_t s, int pack_gsize) {
   // counting form when [tag | H | L] fits 64 bits with counters that can hold a whole bucket
   const char* force = getenv("QH_WINDOW_KERNEL");  // A/B tests: "cas" compare-and-swap kernels, "count" generic counters
   const int tagbits = g.rbits + g.pbits;
@@ -1007,6 +1045,7 @@ void qh_launch_window_build(uint64_t* table, const qh_geom& g, const uint64_t* i
   const bool fits = ring_ok && cb >= 10 && (1ull << cb) > cap + g.max_val + 1;
   // counters narrower than a bucket, but wide enough to be watched (see GUARD)
   const bool guard = !fits && ring_ok && cb >= 11 && (1ull << cb) > 1025 + 2 * (g.max_val + 1) && !(force && !strcmp(force, "noguard"));
+  const bool pk = pack_gsize > 0;
   if ((fits || guard) && !(force && !strcmp(force, "cas"))) {
     // one workgroup per CU walks the windows (see the kernel): QH_WINDOW_GRID overrides the grid for A/B tests
     const char* gs = getenv("QH_WINDOW_GRID");
@@ -1014,30 +1053,33 @@ void qh_launch_window_build(uint64_t* table, const qh_geom& g, const uint64_t* i
     if (grid == 0 || grid > n_windows) grid = n_windows;
     // 16-bit counters: the tag is the high word ("count": the generic form even then)
     const bool cb16 = fits && tagbits <= 32 && 65536ull > cap + g.max_val + 1 && !(force && !strcmp(force, "count"));
-    if (cb16)
-      hipLaunchKernelGGL((k_window_count<true, false>), dim3(grid), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
-                         n_windows, table_dirty, meta, 16, fail, 0u);
-    else if (fits)
-      hipLaunchKernelGGL((k_window_count<false, false>), dim3(grid), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
-                         n_windows, table_dirty, meta, cb, fail, 0u);
-    else
-      hipLaunchKernelGGL((k_window_count<false, true>), dim3(grid), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
-                         n_windows, table_dirty, meta, cb, fail, (uint32_t)((1u << cb) - 1u - 1024u));
+#define QW_COUNT(CB16, GUARD, PACKED, CB, HOT)                                                                            \
+  hipLaunchKernelGGL((k_window_count<CB16, GUARD, PACKED>), dim3(grid), dim3(QP_THREADS), 0, s, table, g, items, cap, counts, \
+                     n_windows, table_dirty, meta, CB, fail, HOT, pack_gsize)
+    const uint32_t hot = (uint32_t)((1u << cb) - 1u - 1024u);
+    if (cb16) { if (pk) QW_COUNT(true, false, true, 16, 0u); else QW_COUNT(true, false, false, 16, 0u); }
+    else if (fits) { if (pk) QW_COUNT(false, false, true, cb, 0u); else QW_COUNT(false, false, false, cb, 0u); }
+    else { if (pk) QW_COUNT(false, true, true, cb, hot); else QW_COUNT(false, true, false, cb, hot); }
+#undef QW_COUNT
     return;
   }
-  if (g.vbits + g.pbits <= 32)
-    hipLaunchKernelGGL((k_window_build<true, false>), dim3(n_windows), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
-                       table_dirty, meta, fail, nullptr, 0u, 0u, 0u);
-  else
-    hipLaunchKernelGGL((k_window_build<false, false>), dim3(n_windows), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
-                       table_dirty, meta, fail, nullptr, 0u, 0u, 0u);
+#define QW_BUILD(NARROW, PACKED)                                                                                          \
+  hipLaunchKernelGGL((k_window_build<NARROW, false, PACKED>), dim3(n_windows), dim3(QP_THREADS), 0, s, table, g, items, cap, \
+                     counts, table_dirty, meta, fail, nullptr, 0u, 0u, 0u, pack_gsize)
+  if (g.vbits + g.pbits <= 32) { if (pk) QW_BUILD(true, true); else QW_BUILD(true, false); }
+  else { if (pk) QW_BUILD(false, true); else QW_BUILD(false, false); }
+#undef QW_BUILD
 }
 
 // The failed windows of a pass again, after the table has grown: buckets made for n_buckets windows, table of
 // n_windows (a power-of-two multiple); prev_fail has the flags of the pass before (n_prev windows).
 void qh_launch_window_redo(uint64_t* table, const qh_geom& g, const uint64_t* items, uint64_t cap,
                            const unsigned long long* counts, uint32_t n_buckets, uint32_t n_windows, uint32_t* fail,
-                           const uint32_t* prev_fail, uint32_t n_prev, qh_meta* meta, hipStream_t s) {
-  hipLaunchKernelGGL((k_window_build<false, true>), dim3(n_windows), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
-                     1, meta, fail, prev_fail, n_prev - 1u, n_buckets - 1u, n_windows - 1u);
+                           const uint32_t* prev_fail, uint32_t n_prev, qh_meta* meta, hipStream_t s, int pack_gsize) {
+  if (pack_gsize > 0)
+    hipLaunchKernelGGL((k_window_build<false, true, true>), dim3(n_windows), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
+                       1, meta, fail, prev_fail, n_prev - 1u, n_buckets - 1u, n_windows - 1u, pack_gsize);
+  else
+    hipLaunchKernelGGL((k_window_build<false, true, false>), dim3(n_windows), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
+                       1, meta, fail, prev_fail, n_prev - 1u, n_buckets - 1u, n_windows - 1u, 0);
 }

@@ -109,6 +109,39 @@ def test_watched_counters_for_wide_tags(monkeypatch):
     assert passes == {"": 2, "noguard": 1}   # the hot window went round again, at the same table size
 
 
+@pytest.mark.parametrize("k,bits,size,chunks", [(12, 7, 1 << 14, 3), (16, 3, 1 << 20, 2), (9, 5, 1 << 16, 1), (17, 12, 1 << 22, 2)])
+def test_packed_window_items(k, bits, size, chunks, monkeypatch):
+    """short remainders (2k + 1 - log2(slots) <= 18): the window buckets hold 32-bit items {remainder | position |
+    quality}. Same table as with 64-bit items (QH_NO_PACK) and as the oracle's, through every window kernel, deferred
+    batches, and -- the (12, 7, 2^14) case -- a table that doubles four times under its reads, whose failed windows are
+    run again from buckets packed for the smaller table."""
+    rng = np.random.default_rng(900 + k)
+    data = random_fastq(rng, 12000, k=k, genome=rng.integers(0, 4, size=150000))
+    db = po.OracleDB(1 << 22, k, bits)
+    n = db.add_fastq(data, 38, threads=4)
+    om, ov = db.sorted_dump()
+    for no_pack in (False, True):
+        if no_pack:
+            monkeypatch.setenv("QH_NO_PACK", "1")
+        for kernel in ("", "count", "cas"):
+            monkeypatch.setenv("QH_WINDOW_KERNEL", kernel)
+            for defer in (0, 1 << 28):
+                h = qa.HashWithQuality(size, 2 * k, bits, min_qual=38)
+                h.set_mode("partition")
+                h.set_defer(defer)
+                recs = data.split(b"@read")[1:]
+                step = (len(recs) + chunks - 1) // chunks
+                for i in range(0, len(recs), step):
+                    h.add_fastq(b"".join(b"@read" + r for r in recs[i:i + step]))
+                st = h.done()
+                m, v = sorted_pairs(*h.dump())
+                assert st["instances"] == n and st["distinct"] == om.size, (no_pack, kernel, defer)
+                assert (m == om).all() and (v == ov).all(), (no_pack, kernel, defer)
+                if size == 1 << 14:
+                    assert st["grows"] >= 3
+                h.close()
+
+
 def test_partitioned_growth_and_contention():
     """a 16384-slot table receiving far more distinct k-mers than it holds: windows overflow, the
     spill list is inserted directly, the table doubles; plus a poly-A read (one slot, 5000 updates)"""
