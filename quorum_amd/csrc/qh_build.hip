@@ -573,7 +573,11 @@ static int run_partitioned(qh_build* h, const part_source& src, size_t max_items
   // measured on MI355X (profiles/): two levels of about equal width beat one 4096-way level
   // (1.29 ms vs 1.97 ms for 152 M items); tables of up to 256 windows use one level
   // (level 1 loses more to a wide split than level 2: at 19 bits 9 + 10 takes 15.9 ms for 1.4 G items, 10 + 9 19.8 ms)
-  int b1 = wid_bits <= 8 ? wid_bits : wid_bits >= 19 ? wid_bits / 2 : (wid_bits + 1) / 2;
+  // Level 1 pays more for every bit than level 2 (2^31 slots, 3.8 G items: level 1 16.6 / 18.7 / 23.5 / 33.7 ms at 7 / 8 / 9 /
+  // 10 bits where its buckets lie badly, 17.4 / 18.5 at 8 / 9 where they lie well; level 2 15.7 / 16.4 /
+  // 17.3 / 22.3 ms at 8 / 9 / 10 / 11): level 1 takes at most 8 bits as long as that leaves level 2 no more than 10
+  int b1 = wid_bits <= 8 ? wid_bits : (wid_bits + 1) / 2;
+  if (b1 > 8) b1 = wid_bits - 10 > 8 ? wid_bits - 10 : 8;
   if (b1 > 12) b1 = 12;
   if (h->level1_bits >= 0 && h->level1_bits <= wid_bits && wid_bits - h->level1_bits <= 12) b1 = h->level1_bits;
   const int b2 = wid_bits - b1;
