@@ -123,13 +123,16 @@ def kernel_table(ktimes, st, steps, single, per_rank_step, shard_bits=0):
     IT must move per k-mer in this three-pass design"""
     avgs = [ms / n if n else 0.0 for ms, n in ktimes]
     partitioned = ktimes[3][1] > 0
+    # window buckets hold 4-byte items when remainder, position and quality bit fit (qh_items_pack_gsize)
+    item_b = 4.0 if 2 * K + 1 - (int(st["slots"]).bit_length() - 1) - shard_bits + 13 + 1 <= 32 else 8.0
     knames = ("segments(k_rec_segs_sum+k_scan_u32+k_rec_segs_apply)" if partitioned and single
               else "k_build_direct" if single else "k_insert_items",
               # (the instantiations rocprofv3 lists for these geometries: k = 24, bin field in the low 32 bits;
               #  the shard handle of the pipeline checks the owner of what it receives)
               "k_partition<0, false, 0, 24, true>" if single else "k_partition<1, true, 0> (level 1)",
               "k_partition<1, false, 0, 0, true>" if single else "k_partition<1, false, 0, 0, true> (level 2)",
-              "k_window_count<true, false>")  # the counting form with 16-bit counters at this geometry
+              # the counting form with 16-bit counters at these geometries, over packed or 8-byte items
+              "k_window_count<true, false, true>" if item_b == 4.0 else "k_window_count<true, false, false>")
     text_b = 2.0 * READ_LEN / KPR
     per_kernel = {}
     for i in range(4):
@@ -138,8 +141,6 @@ def kernel_table(ktimes, st, steps, single, per_rank_step, shard_bits=0):
         launches_per_step = ktimes[i][1] / steps
         per_launch = per_rank_step / max(launches_per_step, 1e-9)   # this rank's insertions per launch of the kernel
         e = {"avg_ms": avgs[i], "launches": int(ktimes[i][1]), "launches_per_step": launches_per_step}
-        # window buckets hold 4-byte items when remainder, position and quality bit fit (qh_items_pack_gsize)
-        item_b = 4.0 if 2 * K + 1 - (int(st["slots"]).bit_length() - 1) - shard_bits + 13 + 1 <= 32 else 8.0
         own = (None, text_b + 8.0, 8.0 + item_b, item_b + 8.0 * st["slots"] / max(1.0, per_launch))[i] if partitioned else None
         if own:
             # level 1: the read's text in, one 8-byte item out; level 2: item in, item out; windows: item in, every

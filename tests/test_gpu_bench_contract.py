@@ -62,7 +62,7 @@ def test_the_drivers_command_on_the_full_workload():
     assert "configs[2]" in cfg["workload"] and cfg["slots_per_gpu"] == 1 << 31 and cfg["pieces_per_gpu"] == 4
     assert 0.97 * 50_000_000 * 77 < cfg["insertions_per_step"] <= 50_000_000 * 77
     assert cfg["window_passes_per_step"] == 1             # the table is streamed once per step, not once per piece
-    win = d["roofline"]["kernels"]["k_window_count<true, false>"]
+    win = d["roofline"]["kernels"]["k_window_count<true, false, true>"]   # packed items at 2^31 slots
     assert win["launches_per_step"] == 1.0
     assert d["value"] > 40e9
     c1 = d["configs1"]
