@@ -221,17 +221,24 @@ __device__ __forceinline__ void qp_spill(const qp_params& p, uint64_t item) {
 // and masks of the extraction loop fold into the instructions.
 // BINLO: the bin field of (hash << 1 | q) lies in the low 32 bits (bin_shift + bin_bits <= 31): one bit-field extract
 // instead of a 64-bit shift and a mask, three times per item.
-template <int SRC, bool OWNER, int KCLASS, int KFIX = 0, bool BINLO = false>
+// BPW, MAXB: 64-item blocks a wave keeps per tile and the most buckets a launch may split into. The tile (16 x BPW x 64
+// items) and the three per-bucket arrays share the CU's LDS: 12 blocks with 4096 buckets by default (a lane of the FASTQ
+// source keeps a segment of QP_SEG = 12 k-mers), 18 blocks with 1024 buckets (156 KiB, 128 VGPRs, nothing spilled) for
+// item sources that split 512 or 1024 ways -- runs half as long again where they are shortest, level 2 of the large
+// tables: 17.4 -> 16.3 ms per configs[2] step; 16 blocks 16.6 ms; no gain at 64 or 128 buckets.
+template <int SRC, bool OWNER, int KCLASS, int KFIX = 0, bool BINLO = false, int BPW = QP_BLOCKS_PER_WAVE, int MAXB = QP_MAX_BINS>
 __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, const qh_geom g) {
   const int K = KFIX ? KFIX : g.k;
   auto bin_of_item = [&](uint64_t item) -> uint32_t {  // item = hash << 1 | q
     return BINLO ? __builtin_amdgcn_ubfe((uint32_t)item, (uint32_t)p.bin_shift + 1u, p.bin_bits)
                  : (uint32_t)((item >> 1) >> p.bin_shift) & p.bin_mask;
   };
-  __shared__ uint64_t sorted[QP_TILE_ITEMS];
-  __shared__ uint32_t cursor[QP_MAX_BINS];  // histogram, then running placement cursor
-  __shared__ uint32_t offs[QP_MAX_BINS];    // exclusive prefix of the histogram
-  __shared__ uint32_t gbase[QP_MAX_BINS];   // reserved start inside the global bucket
+  constexpr uint32_t TILE_ITEMS = QP_WAVES * BPW * 64;
+  static_assert(SRC != QP_SRC_FASTQ || BPW == QP_SEG, "a lane of the FASTQ source keeps one segment");
+  __shared__ uint64_t sorted[TILE_ITEMS];
+  __shared__ uint32_t cursor[MAXB];  // histogram, then running placement cursor
+  __shared__ uint32_t offs[MAXB];    // exclusive prefix of the histogram
+  __shared__ uint32_t gbase[MAXB];   // reserved start inside the global bucket
   __shared__ uint32_t wsum[QP_WAVES];
   __shared__ uint32_t s_total;
 
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
     src = p.in + (uint64_t)blockIdx.y * p.in_cap;
     src_n = p.in_counts ? (uint64_t)p.in_counts[(size_t)blockIdx.y * p.in_count_stride] : p.in_n;
     if (src_n > p.in_cap) src_n = p.in_cap;
-    ntiles = (src_n + QP_TILE_ITEMS - 1) / QP_TILE_ITEMS;
+    ntiles = (src_n + TILE_ITEMS - 1) / TILE_ITEMS;
   }
   const uint32_t in_bucket = SRC == QP_SRC_ITEMS ? blockIdx.y : 0;
 
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
   const uint2 no_seg = make_uint2(0, 0);
   uint2 sd_cur = no_seg, sd_next = no_seg;
   uint4 pl[4];  // words j, j+1 of the v, l0, l1 planes at the sequence offset and of h at the quality offset
-  uint64_t raw[QP_BLOCKS_PER_WAVE];
+  uint64_t raw[BPW];
   auto load_sdesc = [&](uint64_t tile) -> uint2 {
     const uint64_t sidx = tile * QP_THREADS + tid;
     return sidx < nseg ? p.seg_desc[sidx] : no_seg;
@@ -280,9 +287,9 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
     pl[3] = load2(p.planes + p.plane_words + ((sd.x + (sd.y >> 4)) >> 6));
   };
   auto issue_items = [&](uint64_t tile) {
-    const uint64_t j0 = tile * QP_TILE_ITEMS + (uint64_t)wave * (QP_BLOCKS_PER_WAVE * 64) + lane;
+    const uint64_t j0 = tile * TILE_ITEMS + (uint64_t)wave * (BPW * 64) + lane;
 #pragma unroll
-    for (int i = 0; i < QP_BLOCKS_PER_WAVE; ++i) {
+    for (int i = 0; i < BPW; ++i) {
       const uint64_t j = j0 + (uint64_t)i * 64;
       raw[i] = j < src_n ? src[j] : QP_NONE;
     }
@@ -302,11 +309,11 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
     // ---- pass 1: produce this wave's items (kept in registers) and the tile histogram
     // FASTQ source: bit i of live = it[i] holds an item of this shard; item source: QP_NONE marks the others
     // (measured: the mask costs level 2 4 %, the sentinel's initialisation costs level 1 its 12 moves)
-    uint64_t it[QP_BLOCKS_PER_WAVE];
+    uint64_t it[BPW];
     uint32_t live = 0;
     if (SRC == QP_SRC_ITEMS) {
 #pragma unroll
-      for (int i = 0; i < QP_BLOCKS_PER_WAVE; ++i) it[i] = QP_NONE;
+      for (int i = 0; i < BPW; ++i) it[i] = QP_NONE;
     }
 
     if (SRC == QP_SRC_FASTQ) {
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
       sd_next = load_sdesc(tile + 2ull * gridDim.x);
     } else {
 #pragma unroll
-      for (int i = 0; i < QP_BLOCKS_PER_WAVE; ++i) {
+      for (int i = 0; i < BPW; ++i) {
         if (raw[i] != QP_NONE) {
           const uint32_t q = (uint32_t)(raw[i] & 1);
           const uint64_t h = p.in_hashed ? ((raw[i] >> 1) & g.hmask) : qh_hash_key((raw[i] >> 1) & g.kmask, g.k);
@@ -422,7 +429,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_partition(const qp_params p, con
 
     // ---- pass 2: place the items bucket-sorted into LDS
 #pragma unroll
-    for (int i = 0; i < QP_BLOCKS_PER_WAVE; ++i) {
+    for (int i = 0; i < BPW; ++i) {
       if (SRC == QP_SRC_ITEMS ? it[i] != QP_NONE : ((live >> i) & 1u) != 0) {
         sorted[atomicAdd(&cursor[bin_of_item(it[i])], 1u)] = it[i];
       }
@@ -527,7 +534,10 @@ void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsign
   const dim3 grid((unsigned)gx, n_in_buckets), block(QP_THREADS);
   static const char* nobinlo = getenv("QH_NO_BINLO");
   const bool binlo = !nobinlo && d.bin_shift + d.bin_bits <= 31;
+  const char* notall = getenv("QH_NO_TALL_TILE");  // A/B runs (read per launch)
   if (check_owner) hipLaunchKernelGGL((k_partition<QP_SRC_ITEMS, true, 0>), grid, block, 0, s, p, g);
+  else if (binlo && d.bin_bits <= 10 && d.bin_bits >= 9 && !notall)
+    hipLaunchKernelGGL((k_partition<QP_SRC_ITEMS, false, 0, 0, true, 18, 1024>), grid, block, 0, s, p, g);
   else if (binlo) hipLaunchKernelGGL((k_partition<QP_SRC_ITEMS, false, 0, 0, true>), grid, block, 0, s, p, g);
   else hipLaunchKernelGGL((k_partition<QP_SRC_ITEMS, false, 0>), grid, block, 0, s, p, g);
 }
