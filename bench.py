@@ -125,12 +125,16 @@ def kernel_table(ktimes, st, steps, single, per_rank_step, shard_bits=0):
     partitioned = ktimes[3][1] > 0
     # window buckets hold 4-byte items when remainder, position and quality bit fit (qh_items_pack_gsize)
     item_b = 4.0 if 2 * K + 1 - (int(st["slots"]).bit_length() - 1) - shard_bits + 13 + 1 <= 32 else 8.0
+    # the split of the window-id bits as run_partitioned makes it (qh_build.hip): level 2 takes 18-block tiles at 9 or 10 bits
+    wid = int(st["slots"]).bit_length() - 1 - 13
+    b1 = wid if wid <= 8 else min((wid + 1) // 2, max(8, wid - 10))
+    b2 = wid - b1
     knames = ("segments(k_rec_segs_sum+k_scan_u32+k_rec_segs_apply)" if partitioned and single
               else "k_build_direct" if single else "k_insert_items",
-              # (the instantiations rocprofv3 lists for these geometries: k = 24, bin field in the low 32 bits;
-              #  the shard handle of the pipeline checks the owner of what it receives)
-              "k_partition<0, false, 0, 24, true>" if single else "k_partition<1, true, 0> (level 1)",
-              "k_partition<1, false, 0, 0, true>" if single else "k_partition<1, false, 0, 0, true> (level 2)",
+              # (the instantiations rocprofv3 lists for these geometries: k = 24, bin field in the low 32 bits, tile
+              #  blocks and bucket limit; the shard handle of the pipeline checks the owner of what it receives)
+              "k_partition<0, false, 0, 24, true, 12, 4096>" if single else "k_partition<1, true, 0, 0, false, 12, 4096> (level 1)",
+              "k_partition<1, false, 0, 0, true, %s>%s" % ("18, 1024" if 9 <= b2 <= 10 else "12, 4096", "" if single else " (level 2)"),
               # the counting form with 16-bit counters at these geometries, over packed or 8-byte items
               "k_window_count<true, false, true>" if item_b == 4.0 else "k_window_count<true, false, false>")
     text_b = 2.0 * READ_LEN / KPR
