@@ -3,6 +3,8 @@ back -- early preparation --, host-parsed text, mer lists on the host and on the
 switched on the way, collections, lookups on the live table, dumps and resets in between, on tables small enough to grow.
 After every observation the table must equal the oracle's, which received the same inputs one by one
 (hash_with_quality::add is order independent, src/mer_database.hpp:94-113)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -28,8 +30,16 @@ def reads_for(k, seed):
     return synth.make_fastq(g, 260_000, L, err=0.004, n_rate=0.001, seed=seed + 1, tails=True), synth.record_bytes(L)
 
 
-@pytest.mark.parametrize("seed,k,bits,slots", [(1, 24, 7, 1 << 22), (2, 31, 3, 1 << 20), (3, 17, 5, 1 << 23),
-                                               (4, 24, 1, 1 << 18), (5, 31, 12, 1 << 22), (6, 12, 7, 1 << 22)])
+WALKS = [(1, 24, 7, 1 << 22), (2, 31, 3, 1 << 20), (3, 17, 5, 1 << 23), (4, 24, 1, 1 << 18), (5, 31, 12, 1 << 22),
+         (6, 12, 7, 1 << 22)]
+if os.environ.get("QH_WALK_EXTRA"):   # a soak run: QH_WALK_EXTRA=<n> adds n more walks over drawn geometries
+    _r = np.random.default_rng(2024)
+    for _i in range(int(os.environ["QH_WALK_EXTRA"])):
+        WALKS.append((100 + _i, int(_r.choice([9, 12, 15, 17, 20, 24, 27, 31])), int(_r.choice([1, 3, 7, 12, 20])),
+                      1 << int(_r.integers(14, 25))))
+
+
+@pytest.mark.parametrize("seed,k,bits,slots", WALKS)
 def test_random_walk_matches_oracle(seed, k, bits, slots):
     rng = np.random.default_rng(seed)
     fq, RB = reads_for(k, 100 + seed)
@@ -118,5 +128,5 @@ def test_random_walk_matches_oracle(seed, k, bits, slots):
 
 
 def test_the_walks_reached_the_states_they_are_for():
-    assert SEEN["walks"] == 6, "run the whole file"
+    assert SEEN["walks"] == len(WALKS), "run the whole file"
     assert SEEN["early_preps"] > 10 and SEEN["grows"] > 3 and SEEN["window_passes"] > 10, SEEN
