@@ -194,7 +194,7 @@ extern "C" void qh_build_destroy(qh_build* h) {
   void* alts[] = {h->alt.recs, h->alt.tiles, h->alt.nlplane, h->alt.rbsums, h->alt.segdesc, h->alt.planes, h->d_pmeta};
   for (void* p : alts) if (p) { e = hipFree(p); (void)e; }
   void* ptrs[] = {h->table, h->g.wvals, h->d_meta, h->d_chunk, h->d_recs, h->d_tiles, h->d_ovf[0], h->d_ovf[1], h->d_items, h->d_shard_counts, h->d_rbsums, h->d_segdesc, h->d_planes, h->d_nlplane,
-                  h->d_bins[0], h->d_bins[1], h->d_bin_counts[0], h->d_bin_counts[1], h->d_wfail[0], h->d_wfail[1], h->d_bspill};
+                  h->d_bins[0], h->d_bins[1], h->d_bin_counts[0], h->d_bin_counts[1], h->d_wfail[0], h->d_wfail[1], h->d_bspill, h->d_wlist};
   for (void* p : ptrs) if (p) { e = hipFree(p); (void)e; }
   if (h->h_meta) { e = hipHostFree(h->h_meta); (void)e; }
   for (auto& pr : h->evk) for (hipEvent_t ev : pr) if (ev) { e = hipEventDestroy(ev); (void)e; }
@@ -288,8 +288,9 @@ static int resolve_full(qh_build* h, uint64_t n_ovf, uint32_t n_winfail, uint32_
     if (n_winfail) {
       nw = 1u << (h->g.lsize - QH_WINDOW_BITS);
       if ((rc = ensure((void**)&h->d_wfail[wf ^ 1], &h->wfail_cap[wf ^ 1], (size_t)nw * 4, "window flags"))) return rc;
+      if ((rc = ensure((void**)&h->d_wlist, &h->wlist_cap, ((size_t)n_winfail + 1) * 4, "failed windows"))) return rc;
       qh_launch_window_redo(h->table, h->g, h->d_bins[1], h->defer_capw, h->d_bin_counts[1], h->defer_nw, nw,
-                            h->d_wfail[wf ^ 1], h->d_wfail[wf], n_prev, h->d_meta, h->stream, h->defer_pack);
+                            h->d_wfail[wf ^ 1], h->d_wfail[wf], n_prev, n_winfail, h->d_wlist, h->d_meta, h->stream, h->defer_pack);
       h->st.window_passes += 1;
     }
     QH_HIP(hipGetLastError());

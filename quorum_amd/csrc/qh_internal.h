@@ -63,6 +63,7 @@ struct qh_build {
   uint64_t* d_bspill = nullptr; size_t bspill_cap = 0;           // items that overflowed a bucket, of the whole batch (bytes)
   uint64_t bspill_n = 0;
   uint32_t* d_wfail[2] = {nullptr, nullptr}; size_t wfail_cap[2] = {0, 0};  // per window: the pass left it as it was
+  uint32_t* d_wlist = nullptr; size_t wlist_cap = 0;  // the failed windows of a pass, for the pass that runs them again
   bool pending_deferred = false; // the chunk in flight went into the open batch
   size_t pending_fastq_len = 0;  // bytes of the FASTQ chunk in flight (items per byte are learnt at collection)
   double items_per_byte = 0;     // largest ratio seen so far: sizes a batch better than the len / 2 bound

@@ -118,9 +118,11 @@ void qh_launch_partition_items(const uint64_t* in, uint64_t in_cap, const unsign
 void qh_launch_window_build(uint64_t* table, const qh_geom& g, const uint64_t* items, uint64_t cap,
                             const unsigned long long* counts, uint32_t n_windows, int table_state, uint32_t* fail,
                             qh_meta* meta, hipStream_t s, int pack_gsize = 0);
+// n_failed: how many flags of prev_fail are set (the pass counted them); list: n_failed + 1 words of scratch
 void qh_launch_window_redo(uint64_t* table, const qh_geom& g, const uint64_t* items, uint64_t cap,
                            const unsigned long long* counts, uint32_t n_buckets, uint32_t n_windows, uint32_t* fail,
-                           const uint32_t* prev_fail, uint32_t n_prev, qh_meta* meta, hipStream_t s, int pack_gsize = 0);
+                           const uint32_t* prev_fail, uint32_t n_prev, uint32_t n_failed, uint32_t* list, qh_meta* meta,
+                           hipStream_t s, int pack_gsize = 0);
 
 // largest bucket capacity for which qh_launch_window_build still takes its fastest counting kernel at this geometry
 // (counters must stay above a bucket's fill); 0 = the capacity does not change the kernel

@@ -588,11 +588,20 @@ __global__ __launch_bounds__(QP_THREADS) void k_window_build(uint64_t* __restric
                                                              int table_dirty, qh_meta* __restrict__ meta,
                                                              uint32_t* __restrict__ fail,
                                                              const uint32_t* __restrict__ prev_fail, uint32_t prev_mask,
-                                                             uint32_t bucket_mask, uint32_t win_mask, int pk_gsize) {
+                                                             uint32_t bucket_mask, uint32_t win_mask, int pk_gsize,
+                                                             const uint32_t* __restrict__ wlist, uint32_t child_shift) {
   __shared__ uint64_t win[1u << QH_WINDOW_BITS];
   __shared__ uint64_t ring[QP_WAVES][QW_RING];  // window + rings = half of the CU's LDS: two workgroups per CU
   uint32_t* wnew = reinterpret_cast<uint32_t*>(&ring[0][0]);  // reused once the rings have drained
-  const uint32_t w = blockIdx.x;
+  // FILTER with a list: workgroup i runs child (i mod 2^child_shift) of the failed window wlist[i >> child_shift] of the
+  // pass before (the windows w of the grown table with w & prev_mask == that window); every other window's flag was
+  // cleared by the host
+  uint32_t w = blockIdx.x;
+  if (FILTER && wlist) {
+    const uint32_t parent = wlist[blockIdx.x >> child_shift];
+    if (parent == 0xFFFFFFFFu) return;  // (a list shorter than the host's count: nothing to run)
+    w = parent + (blockIdx.x & ((1u << child_shift) - 1u)) * (prev_mask + 1u);
+  }
   const uint32_t bkt = FILTER ? w & bucket_mask : w;
   if (FILTER && prev_fail[w & prev_mask] == 0) {  // the window this one descends from went through
     if (threadIdx.x == 0) fail[w] = 0;
@@ -1075,21 +1084,46 @@ void qh_launch_window_build(uint64_t* table, const qh_geom& g, const uint64_t* i
   }
 #define QW_BUILD(NARROW, PACKED)                                                                                          \
   hipLaunchKernelGGL((k_window_build<NARROW, false, PACKED>), dim3(n_windows), dim3(QP_THREADS), 0, s, table, g, items, cap, \
-                     counts, table_dirty, meta, fail, nullptr, 0u, 0u, 0u, pack_gsize)
+                     counts, table_dirty, meta, fail, nullptr, 0u, 0u, 0u, pack_gsize, nullptr, 0u)
   if (g.vbits + g.pbits <= 32) { if (pk) QW_BUILD(true, true); else QW_BUILD(true, false); }
   else { if (pk) QW_BUILD(false, true); else QW_BUILD(false, false); }
 #undef QW_BUILD
 }
 
-// The failed windows of a pass again, after the table has grown: buckets made for n_buckets windows, table of
-// n_windows (a power-of-two multiple); prev_fail has the flags of the pass before (n_prev windows).
+// the windows whose flag is set, in any order; list[cap] counts them (list preset to ~0 by the caller)
+__global__ __launch_bounds__(256) void k_failed_windows(const uint32_t* __restrict__ fail, uint32_t n,
+                                                        uint32_t* __restrict__ list, uint32_t cap) {
+  for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < n; w += gridDim.x * 256) {
+    if (fail[w]) {
+      const uint32_t at = atomicAdd(&list[cap], 1u);
+      if (at < cap) list[at] = w;
+    }
+  }
+}
+
+// The failed windows of a pass again, after the table has grown (or, for windows that only met a hot key, at the same
+// size): buckets made for n_buckets windows, table of n_windows (a power-of-two multiple); prev_fail has the flags of
+// the pass before (n_prev windows), n_failed of them set. `list` (n_failed + 1 words) receives the failed windows, and
+// only their descendants get a workgroup: a launch over all 2^16 windows of a 2^29-slot table took 0.18 ms to find
+// the handful that had anything to do.
 void qh_launch_window_redo(uint64_t* table, const qh_geom& g, const uint64_t* items, uint64_t cap,
                            const unsigned long long* counts, uint32_t n_buckets, uint32_t n_windows, uint32_t* fail,
-                           const uint32_t* prev_fail, uint32_t n_prev, qh_meta* meta, hipStream_t s, int pack_gsize) {
+                           const uint32_t* prev_fail, uint32_t n_prev, uint32_t n_failed, uint32_t* list, qh_meta* meta,
+                           hipStream_t s, int pack_gsize) {
+  hipError_t e = hipMemsetAsync(list, 0xFF, (size_t)n_failed * 4, s);
+  if (e == hipSuccess) e = hipMemsetAsync(list + n_failed, 0, 4, s);
+  if (e == hipSuccess) e = hipMemsetAsync(fail, 0, (size_t)n_windows * 4, s);
+  (void)e;  // (the caller checks hipGetLastError)
+  uint32_t cg = (n_prev + 255) / 256;
+  if (cg > 1024) cg = 1024;
+  hipLaunchKernelGGL(k_failed_windows, dim3(cg), dim3(256), 0, s, prev_fail, n_prev, list, n_failed);
+  uint32_t child_shift = 0;
+  while ((n_prev << child_shift) < n_windows) ++child_shift;
+  const dim3 grid(n_failed << child_shift);
   if (pack_gsize > 0)
-    hipLaunchKernelGGL((k_window_build<false, true, true>), dim3(n_windows), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
-                       1, meta, fail, prev_fail, n_prev - 1u, n_buckets - 1u, n_windows - 1u, pack_gsize);
+    hipLaunchKernelGGL((k_window_build<false, true, true>), grid, dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
+                       1, meta, fail, prev_fail, n_prev - 1u, n_buckets - 1u, n_windows - 1u, pack_gsize, list, child_shift);
   else
-    hipLaunchKernelGGL((k_window_build<false, true, false>), dim3(n_windows), dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
-                       1, meta, fail, prev_fail, n_prev - 1u, n_buckets - 1u, n_windows - 1u, 0);
+    hipLaunchKernelGGL((k_window_build<false, true, false>), grid, dim3(QP_THREADS), 0, s, table, g, items, cap, counts,
+                       1, meta, fail, prev_fail, n_prev - 1u, n_buckets - 1u, n_windows - 1u, 0, list, child_shift);
 }
