@@ -447,8 +447,6 @@ static size_t est_fastq_items(const qh_build* h, size_t len) {
   return e < ub ? e : ub;
 }
 
-// Before a chunk is enqueued: the chunk in flight is collected; an open batch of deferred chunks is flushed when this
-// chunk does not go into it (direct path) or does not fit it any more.
 extern "C" int qh_build_set_defer(qh_build* h, long long max_bytes) {
   if (!h) return qh_fail(QH_EBADARG, "null handle");
   int rc = qh_build_sync(h);  // an open batch was sized under the old budget
@@ -457,6 +455,8 @@ extern "C" int qh_build_set_defer(qh_build* h, long long max_bytes) {
   return QH_OK;
 }
 
+// Before a chunk is enqueued: the chunk in flight is collected; an open batch of deferred chunks is flushed when this
+// chunk does not go into it (direct path) or does not fit it any more.
 static int begin_chunk(qh_build* h, size_t max_items, size_t est_items) {
   int rc = sync_impl(h, false);
   if (rc) return rc;
@@ -476,7 +476,7 @@ static int begin_chunk(qh_build* h, size_t max_items, size_t est_items) {
 
 // ------------------------------------------------- radix-partitioned chunk path
 
-// A chunk goes through the partitioned build when the table has enough 16384-slot
+// A chunk goes through the partitioned build when the table has enough 8192-slot
 // windows to fill the chip and the chunk is large enough to amortise one read+write
 // of the table (16 B/slot); small chunks into big tables stay on the direct path.
 static bool use_partition(const qh_build* h, size_t max_items) {
