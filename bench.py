@@ -100,6 +100,9 @@ def make_c2(rank, world, dev, reads_rank, piece_reads):
 def measure(b, pieces, piece_reads, steps, warmup, fence):
     """-> (seconds of `steps` steps, kernel times, stats of the last step)"""
     def step():
+        # (every step is collected before the next begins. Enqueued back to back instead -- reset() notes itself while
+        #  work is in flight, flush() starts the pass over the table without waiting -- the steps take the same time:
+        #  the pass over the table keeps every CU's LDS, nothing of the next step can run beside it; DESIGN section 6)
         b.reset()
         for piece, n in zip(pieces, piece_reads):
             b.add_fastq_device(piece, max_items=n * KPR)

@@ -147,8 +147,16 @@ int qh_build_sync(qh_build* h);
 int qh_build_finish(qh_build* h, qh_build_stats* stats);
 int qh_build_get_stats(qh_build* h, qh_build_stats* stats);
 
-/* Empty the table and counters (used between benchmark steps). */
+/* Empty the table and counters (a new database in the same handle; used between benchmark steps). With work in flight
+ * on the handle's own stream the reset is noted and applied when that work is collected by the next call, so that a
+ * FASTQ chunk handed over next is prepared beside it (qh_build_add_fastq_device); an error of the work in flight is
+ * then returned by that next call. No upstream counterpart. */
 int qh_build_reset(qh_build* h);
+
+/* Starts the pass over the table for what waits in the window buckets (qh_build_set_defer) and returns without
+ * waiting; the next call that collects (qh_build_sync, an add, get_stats, ...) waits for it. qh_build_sync alone does
+ * both. No upstream counterpart. */
+int qh_build_flush(qh_build* h);
 
 /* hash_with_quality::write(os, &header) (src/mer_database.hpp:115-126) with
  * header.fill_standard()/set_cmdline (src/create_database.cc:100-102). */

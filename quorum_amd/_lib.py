@@ -76,6 +76,7 @@ SIGNATURES = [
     ("qh_build_finish", C.c_int, [_p, C.POINTER(QhBuildStats)]),
     ("qh_build_get_stats", C.c_int, [_p, C.POINTER(QhBuildStats)]),
     ("qh_build_reset", C.c_int, [_p]),
+    ("qh_build_flush", C.c_int, [_p]),
     ("qh_build_write", C.c_int, [_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p)]),
     ("qh_build_write_shard", C.c_int, [_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_int]),
     ("qh_build_grow_to", C.c_int, [_p, C.c_int]),

@@ -330,8 +330,9 @@ static void fold_prep_timing(qh_build* h) {
   }
 }
 
-static int sync_impl(qh_build* h, bool flush) {
-  if (!h) return qh_fail(QH_EBADARG, "null handle");
+static void apply_reset(qh_build* h);
+
+static int sync_core(qh_build* h, bool flush) {
   if (h->failed) return qh_fail(h->failed, "%s", h->failed_msg.c_str());
   for (;;) {
     if (flush && h->defer_open) { int frc = launch_flush(h, false); if (frc) return frc; }
@@ -393,6 +394,20 @@ static int sync_impl(qh_build* h, bool flush) {
     if (rc) { h->failed = rc; h->failed_msg = g_last_error; }
     return rc;
   }
+}
+
+// Collects the chunk in flight (flush: after the window pass over what waits in the buckets). A reset that was asked
+// for while a chunk was in flight (qh_build_reset) is applied here, once that chunk has been collected: what waited in
+// the buckets goes with the table.
+static int sync_impl(qh_build* h, bool flush) {
+  if (!h) return qh_fail(QH_EBADARG, "null handle");
+  if (h->reset_pending) {
+    h->reset_pending = false;
+    const int rc = h->pending ? sync_core(h, false) : QH_OK;
+    if (rc && rc != QH_EFORMAT) return rc;  // (what qh_build_reset itself reports when it collects)
+    apply_reset(h);
+  }
+  return sync_core(h, flush);
 }
 
 extern "C" int qh_build_sync(qh_build* h) { return sync_impl(h, true); }
@@ -497,7 +512,7 @@ static bool use_partition(const qh_build* h, size_t max_items) {
 static int fastq_aux(qh_build* h, size_t buf_len, size_t rec_cap, size_t max_bases, qh_fastq_aux* a) {
   const size_t segs = max_bases / QH_SEG_KMERS + rec_cap, plane_words = (buf_len + 16383) / 16384 * 256 + 2;  // whole 16 KiB tiles (k_index_text stores a tile's planes in 16-byte pieces), even
   int rc;
-  if ((rc = ensure((void**)&h->d_rbsums, &h->rbsums_cap, (rec_cap / 1024 + 4) * 4, "segment sums"))) return rc;
+  if ((rc = ensure((void**)&h->d_rbsums, &h->rbsums_cap, (rec_cap / 1024 + 4 + QH_SCAN_SCRATCH) * 4, "segment sums"))) return rc;
   if ((rc = ensure((void**)&h->d_segdesc, &h->segdesc_cap, (segs + 2) * 8, "segment descriptors"))) return rc;
   if ((rc = ensure((void**)&h->d_planes, &h->planes_cap, plane_words * 32, "bit planes"))) return rc;
   *a = {h->d_rbsums, h->d_segdesc, h->d_planes, plane_words};
@@ -550,6 +565,10 @@ static int launch_flush(qh_build* h, bool same_epoch) {
   qh_launch_window_build(h->table, h->g, h->d_bins[1], h->defer_capw, h->d_bin_counts[1], h->defer_nw,
                          (h->table_dirty ? 1 : 0) | (h->zero_pending ? 2 : 0), h->d_wfail[0], h->d_meta, h->stream, h->defer_pack);
   timing_end(h, 3);
+  // an early preparation (qh_build_add_fastq_device) waits for this pass to end: the pass keeps every CU's LDS, and
+  // swarms of small workgroups from the other stream slipping in as its workgroups retire left it at half its
+  // occupancy (measured: 17.8 instead of 10.7 ms for the 2^31-slot table)
+  if (h->main_mark) QH_HIP(hipEventRecord(h->main_mark, h->stream));
   h->zero_pending = false;  // every window has been written
   // items that overflowed a bucket (the last chunk's, then the batch's list): plain global-CAS insertion
   qh_launch_insert_items(h->defer_spill, h->defer_spill_cap, reinterpret_cast<const unsigned long long*>(&h->d_meta->spill_count),
@@ -710,7 +729,7 @@ extern "C" int qh_build_add_fastq_device(qh_build* h, const void* dev_buf, size_
     std::swap(h->d_segdesc, h->alt.segdesc); std::swap(h->segdesc_cap, h->alt.segdesc_cap);
     std::swap(h->d_planes, h->alt.planes); std::swap(h->planes_cap, h->alt.planes_cap);
     qh_fastq_aux aux;
-    if ((rc = ensure((void**)&h->d_tiles, &h->tile_cap, (ntiles + 1) * 4, "tile counts"))) return rc;
+    if ((rc = ensure((void**)&h->d_tiles, &h->tile_cap, (ntiles + 1 + QH_SCAN_SCRATCH) * 4, "tile counts"))) return rc;
     if ((rc = ensure((void**)&h->d_recs, &h->rec_cap, rec_cap * 16, "record table"))) return rc;
     if ((rc = ensure((void**)&h->d_nlplane, &h->nlplane_cap, (len / 16 + 2) * 8 + 8192, "newline lists"))) return rc;
     if ((rc = fastq_aux(h, len, rec_cap, len / 2, &aux))) return rc;
@@ -736,7 +755,7 @@ extern "C" int qh_build_add_fastq_device(qh_build* h, const void* dev_buf, size_
     QH_HIP(hipMemcpyAsync(h->d_meta, h->d_pmeta, 16, hipMemcpyDeviceToDevice, h->stream));
   } else {
     if ((rc = begin_chunk(h, len / 2, est))) return rc;
-    if ((rc = ensure((void**)&h->d_tiles, &h->tile_cap, (ntiles + 1) * 4, "tile counts"))) return rc;
+    if ((rc = ensure((void**)&h->d_tiles, &h->tile_cap, (ntiles + 1 + QH_SCAN_SCRATCH) * 4, "tile counts"))) return rc;
     if ((rc = ensure((void**)&h->d_recs, &h->rec_cap, rec_cap * 16, "record table"))) return rc;
     if ((rc = ensure((void**)&h->d_nlplane, &h->nlplane_cap, (len / 16 + 2) * 8 + 8192, "newline lists"))) return rc;
   }
@@ -1083,7 +1102,7 @@ extern "C" int qh_build_extract_partitioned_device(qh_build* h, const void* dev_
   QH_HIP(hipMemsetAsync(h->d_meta, 0, sizeof(qh_meta), h->stream));
   const size_t ntiles = (len + QH_TILE_BYTES - 1) / QH_TILE_BYTES;
   const size_t rec_cap = len / 16 + 16;
-  if ((rc = ensure((void**)&h->d_tiles, &h->tile_cap, (ntiles + 1) * 4, "tile counts"))) return rc;
+  if ((rc = ensure((void**)&h->d_tiles, &h->tile_cap, (ntiles + 1 + QH_SCAN_SCRATCH) * 4, "tile counts"))) return rc;
   if ((rc = ensure((void**)&h->d_recs, &h->rec_cap, rec_cap * 16, "record table"))) return rc;
   if ((rc = ensure((void**)&h->d_nlplane, &h->nlplane_cap, (len / 16 + 2) * 8 + 8192, "newline lists"))) return rc;
   qh_fastq_aux aux;
@@ -1169,10 +1188,7 @@ extern "C" int qh_build_finish(qh_build* h, qh_build_stats* stats) {
   return rc;
 }
 
-extern "C" int qh_build_reset(qh_build* h) {
-  if (!h) return qh_fail(QH_EBADARG, "null handle");
-  if (h->pending) { int rc = sync_impl(h, false); if (rc && rc != QH_EFORMAT) return rc; }
-  QH_HIP(hipSetDevice(h->device));
+static void apply_reset(qh_build* h) {
   h->zero_pending = true;  // cleared by the next partitioned chunk's window pass, or by materialize()
   const uint64_t slots = h->st.slots, grows = h->st.grows;
   memset(&h->st, 0, sizeof h->st);
@@ -1183,7 +1199,31 @@ extern "C" int qh_build_reset(qh_build* h) {
   h->defer_items = 0;
   h->bspill_n = 0;
   h->pending_deferred = false;
+}
+
+// With a chunk or a window pass in flight on the handle's own stream the reset is only noted: it is applied when that
+// work is collected, by whatever call comes next -- a FASTQ chunk handed over next is prepared beside it meanwhile
+// (early preparation). An error of the work in flight that qh_build_reset would have returned is then returned by that
+// next call.
+extern "C" int qh_build_reset(qh_build* h) {
+  if (!h) return qh_fail(QH_EBADARG, "null handle");
+  if (h->pending && !h->failed && h->stream == h->own_stream && !getenv("QH_NO_EARLY_PREP")) {
+    h->reset_pending = true;
+    return QH_OK;
+  }
+  if (h->pending) { int rc = sync_impl(h, false); if (rc && rc != QH_EFORMAT) return rc; }
+  h->reset_pending = false;
+  apply_reset(h);
   return QH_OK;
+}
+
+// Starts the window pass over what waits in the buckets and returns; the next call that collects waits for it.
+extern "C" int qh_build_flush(qh_build* h) {
+  if (!h) return qh_fail(QH_EBADARG, "null handle");
+  if (h->failed) return qh_fail(h->failed, "%s", h->failed_msg.c_str());
+  if (h->reset_pending || !h->defer_open) return QH_OK;
+  // (a chunk in flight is the one that filled the buckets last: its counters are still being gathered in d_meta)
+  return launch_flush(h, h->pending);
 }
 
 static int write_all(int fd, const void* p, size_t n, off_t off) {

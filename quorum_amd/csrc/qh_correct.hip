@@ -1383,7 +1383,7 @@ static int correct_device_on(qh_corrector* c, const void* dev_buf, size_t len) {
   int rc;
   const size_t ntiles = (len + QH_TILE_BYTES - 1) / QH_TILE_BYTES;
   const size_t rec_cap = len / 16 + 16;
-  if ((rc = ensure_dev((void**)&c->d_tiles, &c->tile_cap, (ntiles + 1) * 4, "tile counts"))) return rc;
+  if ((rc = ensure_dev((void**)&c->d_tiles, &c->tile_cap, (ntiles + 1 + QH_SCAN_SCRATCH) * 4, "tile counts"))) return rc;
   if ((rc = ensure_dev((void**)&c->d_recs, &c->rec_cap, rec_cap * 16, "record table"))) return rc;
   if ((rc = ensure_dev((void**)&c->d_nlplane, &c->nlplane_cap, (len / 16 + 2) * 8 + 8192, "newline lists"))) return rc;
   QH_HIP(hipEventRecord(c->ev[0], c->stream));

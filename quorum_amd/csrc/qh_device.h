@@ -92,6 +92,80 @@ __device__ __forceinline__ uint32_t block_scan_u32(uint32_t* __restrict__ v, uin
   return carry;
 }
 
+// ---- exclusive scan of a long u32 array by many small workgroups (three launches: block sums, their scan, apply).
+// The one-workgroup scan above keeps 128 KiB of LDS, which no CU has to spare while a partition or window kernel of
+// another chunk runs there: the preparation of the next chunk would wait for that kernel to end. These kernels keep a
+// few bytes of LDS each. `sums` is scratch of ceil(n / QS_BLOCK) + 1 words.
+#define QS_BLOCK 2048u   // values per workgroup of 256 threads
+#define QS_MAX_BLOCKS 1024u
+
+// n_eff = min(n, ceil(*bound / bound_div)) when bound != nullptr (values past it are zero and nobody reads their prefix)
+__device__ __forceinline__ uint32_t qs_n_eff(uint32_t n, const uint32_t* bound, uint32_t bound_div) {
+  if (!bound) return n;
+  const uint32_t used = (*bound + bound_div - 1) / bound_div;
+  return used < n ? used : n;
+}
+
+__device__ __forceinline__ void qs_block_sums(const uint32_t* __restrict__ v, uint32_t n, uint32_t* __restrict__ sums) {
+  __shared__ uint32_t ws[4];
+  const uint32_t base = blockIdx.x * QS_BLOCK;
+  uint32_t t = 0;
+  for (uint32_t i = threadIdx.x; i < QS_BLOCK; i += 256) t += base + i < n ? v[base + i] : 0u;
+  t = wave_sum_u32(t);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// one workgroup of 1024 threads: sums[0, nb) -> their exclusive prefix; returns the total to every thread
+__device__ __forceinline__ uint32_t qs_top(uint32_t* __restrict__ sums, uint32_t nb) {
+  __shared__ uint32_t wt[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t x = threadIdx.x < nb ? sums[threadIdx.x] : 0u;
+  uint32_t inc = x;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += y;
+  }
+  if (lane == 63) wt[wave] = inc;
+  __syncthreads();
+  uint32_t wbase = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const uint32_t y = wt[w];
+    if (w < wave) wbase += y;
+    total += y;
+  }
+  if (threadIdx.x < nb) sums[threadIdx.x] = wbase + inc - x;
+  return total;
+}
+
+// block b of v: exclusive scan in place, offset by sums[b] (thread t owns values [8t, 8t + 8) of the block)
+__device__ __forceinline__ void qs_apply(uint32_t* __restrict__ v, uint32_t n, const uint32_t* __restrict__ sums) {
+  __shared__ uint32_t wt[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t base = blockIdx.x * QS_BLOCK + threadIdx.x * 8u;
+  uint32_t c[8], s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { c[i] = base + i < n ? v[base + i] : 0u; s += c[i]; }
+  uint32_t inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += y;
+  }
+  if (lane == 63) wt[wave] = inc;
+  __syncthreads();
+  uint32_t run = sums[blockIdx.x] + inc - s;
+  for (int w = 0; w < wave; ++w) run += wt[w];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (base + i < n) v[base + i] = run;
+    run += c[i];
+  }
+}
+
 // 16-bit mask of the bytes of v that equal '\n'
 __device__ __forceinline__ uint32_t nl_mask16(uint4 v) {
   uint32_t w[4] = {v.x, v.y, v.z, v.w};

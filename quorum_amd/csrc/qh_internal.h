@@ -40,6 +40,7 @@ struct qh_build {
     uint64_t* planes = nullptr; size_t planes_cap = 0;
   } alt;
   hipStream_t pstream = nullptr;     // stream of the early preparation
+  bool reset_pending = false;                // qh_build_reset was called with a chunk in flight: applied when that chunk is collected
   hipEvent_t prep_done = nullptr;
   hipEvent_t main_mark = nullptr;            // on the main stream: the point of the chunk in flight after which the next chunk's early preparation may start
   qh_meta* d_pmeta = nullptr;        // its own counters (lines, records, format verdict), copied into d_meta afterwards

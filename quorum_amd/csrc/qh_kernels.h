@@ -79,6 +79,8 @@ struct qh_part_dst {
   // table's lsize + shard_bits, the shift that yields the remainder). Items that do not fit a bucket are spilled whole.
   int32_t pack_gsize;
 };
+// words of scratch that qh_launch_index_fastq / qh_launch_segments use behind the (n + 1) counts they scan
+#define QH_SCAN_SCRATCH 1024u
 #define QH_COUNT_STRIDE 513u
 // Window buckets can hold packed items when remainder, position and quality bit fit 32 bits (k = 24 from 2^30 slots on,
 // shorter mers earlier): returns the gsize to pack with, or 0. The buckets are the bulk of the partitioned build's

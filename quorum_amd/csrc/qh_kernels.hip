@@ -126,12 +126,18 @@ __global__ __launch_bounds__(QH_BLOCK) void k_index_text(const uint8_t* __restri
   for (uint32_t i = tid; i < nst; i += QH_BLOCK) dst[i] = stage[i];
 }
 
-// pass 2: exclusive scan of the tile counts (one workgroup), chunk-level checks
-__global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ tile_counts, uint32_t ntiles,
-                                                     const uint8_t* __restrict__ buf, size_t len,
-                                                     uint32_t rec_cap, qh_meta* __restrict__ meta) {
-  __shared__ uint32_t part[1024];
-  const uint32_t total_lines = block_scan_u32(tile_counts, ntiles, part);
+// pass 2: exclusive scan of the tile counts (block sums, their scan with the chunk-level checks, apply: small
+// workgroups that fit beside another chunk's partition kernel, see qh_device.h)
+__global__ __launch_bounds__(256) void k_scan_tiles_sums(const uint32_t* __restrict__ tile_counts, uint32_t ntiles,
+                                                         uint32_t* __restrict__ sums) {
+  qs_block_sums(tile_counts, ntiles, sums);
+}
+
+__global__ __launch_bounds__(1024) void k_scan_tiles_top(uint32_t* __restrict__ tile_counts, uint32_t ntiles,
+                                                         uint32_t* __restrict__ sums, uint32_t nb,
+                                                         const uint8_t* __restrict__ buf, size_t len,
+                                                         uint32_t rec_cap, qh_meta* __restrict__ meta) {
+  const uint32_t total_lines = qs_top(sums, nb);
   if (threadIdx.x == 1023) {
     uint32_t lines = total_lines;
     if (len > 0 && buf[len - 1] != '\n') ++lines;  // last line without '\n'
@@ -146,6 +152,11 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ tile
     meta->format_err = err;
     meta->first_bad = err ? 0 : 0xFFFFFFFFu;
   }
+}
+
+__global__ __launch_bounds__(256) void k_scan_tiles_apply(uint32_t* __restrict__ tile_counts, uint32_t ntiles,
+                                                          const uint32_t* __restrict__ sums) {
+  qs_apply(tile_counts, ntiles, sums);
 }
 
 // a newline at byte p ends line L: the matching field of record L/4 (word L of the record table, returned) and
@@ -213,7 +224,12 @@ void qh_launch_index_fastq(const uint8_t* buf, size_t len, uint32_t* tile_counts
                        reinterpret_cast<uint16_t*>(nl_plane),
                        planes ? reinterpret_cast<uint16_t*>(planes->planes) : nullptr,
                        planes ? (size_t)planes->plane_words * 4 : 0, min_qual, meta);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_counts, ntiles, buf, len, rec_cap, meta);
+  // (tile_counts has room for ntiles + 1 counts and QH_SCAN_SCRATCH words of scratch behind them)
+  uint32_t* sums = tile_counts + ntiles + 1;
+  const uint32_t nb = (ntiles + QS_BLOCK - 1) / QS_BLOCK;
+  if (nb) hipLaunchKernelGGL(k_scan_tiles_sums, dim3(nb), dim3(256), 0, s, tile_counts, ntiles, sums);
+  hipLaunchKernelGGL(k_scan_tiles_top, dim3(1), dim3(1024), 0, s, tile_counts, ntiles, sums, nb, buf, len, rec_cap, meta);
+  if (nb) hipLaunchKernelGGL(k_scan_tiles_apply, dim3(nb), dim3(256), 0, s, tile_counts, ntiles, sums);
   if (ntiles)
     hipLaunchKernelGGL(k_fill_records, dim3(ntiles), dim3(QH_BLOCK), 0, s, buf, len,
                        reinterpret_cast<const uint16_t*>(nl_plane), tile_counts, reinterpret_cast<uint32_t*>(recs), rec_cap, meta);

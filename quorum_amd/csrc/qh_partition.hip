@@ -73,20 +73,28 @@ __global__ __launch_bounds__(256) void k_rec_segs_sum(const uint4* __restrict__ 
   if (threadIdx.x == 0) tile_sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-// exclusive scan of the segment counts of n tiles of records in place by one workgroup; the total goes to v[n].
-// n comes from the record table's capacity (a record per 16 bytes of text); only the tiles that hold records are
-// scanned (the others hold zero and nobody reads their prefix): a twelfth of them for 100-base reads
-__global__ __launch_bounds__(1024) void k_scan_u32(uint32_t* __restrict__ v, uint32_t n, const qh_meta* __restrict__ meta) {
-  __shared__ uint32_t part[1024];
-  const uint32_t used = meta->format_err ? 0u : (meta->nrec + RB_TILE - 1) / RB_TILE;
-  const uint32_t total = block_scan_u32(v, used < n ? used : n, part);
+// exclusive scan of the segment counts of n tiles of records in place; the total goes to v[n] (block sums, their scan,
+// apply: qh_device.h). n comes from the record table's capacity (a record per 16 bytes of text); only the tiles that
+// hold records are scanned (the others hold zero and nobody reads their prefix): a twelfth of them for 100-base reads
+__global__ __launch_bounds__(256) void k_scan_u32_sums(const uint32_t* __restrict__ v, uint32_t n, uint32_t* __restrict__ sums,
+                                                       const qh_meta* __restrict__ meta) {
+  qs_block_sums(v, qs_n_eff(n, &meta->nrec, RB_TILE), sums);
+}
+__global__ __launch_bounds__(1024) void k_scan_u32_top(uint32_t* __restrict__ v, uint32_t n, uint32_t* __restrict__ sums, uint32_t nb) {
+  const uint32_t total = qs_top(sums, nb);
   if (threadIdx.x == 1023) v[n] = total;
+}
+__global__ __launch_bounds__(256) void k_scan_u32_apply(uint32_t* __restrict__ v, uint32_t n, const uint32_t* __restrict__ sums,
+                                                        const qh_meta* __restrict__ meta) {
+  qs_apply(v, qs_n_eff(n, &meta->nrec, RB_TILE), sums);
 }
 
 __global__ __launch_bounds__(256) void k_rec_segs_apply(const uint4* __restrict__ recs, qh_meta* __restrict__ meta,
                                                         const uint32_t* __restrict__ tile_sums, uint32_t k,
                                                         uint2* __restrict__ seg_desc) {
-  constexpr uint32_t SEG_STAGE = 3072;  // 256 reads of 100 to 150 bases make 1800 to 3100 segments
+  // 128 reads a round (half the workgroup computes, all of it copies out): 128 reads of 100 to 150 bases make 900 to
+  // 1300 segments, and the 12 KiB stage fits beside another chunk's level-1 kernel (147.5 of the CU's 160 KiB)
+  constexpr uint32_t SEG_STAGE = 1536, SEG_ROUND = 128;
   __shared__ uint32_t wtot[4];
   __shared__ uint2 stage[SEG_STAGE];
   const uint32_t nrec = meta->format_err ? 0 : meta->nrec;
@@ -94,9 +102,9 @@ __global__ __launch_bounds__(256) void k_rec_segs_apply(const uint4* __restrict_
   if (base >= nrec) return;
   uint32_t srun = tile_sums[blockIdx.x];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (uint32_t j = 0; j < RB_TILE; j += 256) {
+  for (uint32_t j = 0; j < RB_TILE; j += SEG_ROUND) {
     const uint32_t r = base + j + threadIdx.x;
-    const uint4 rc = r < nrec ? recs[r] : make_uint4(0, 0, 0, 0);
+    const uint4 rc = threadIdx.x < SEG_ROUND && r < nrec ? recs[r] : make_uint4(0, 0, 0, 0);
     const uint32_t cs = rec_nsegs(rc.y, k);
     uint32_t sinc = cs;
 #pragma unroll
@@ -169,7 +177,12 @@ void qh_launch_segments(const uint4* recs, uint32_t rec_cap, qh_meta* meta, cons
   hipLaunchKernelGGL(k_rec_segs_sum, dim3(ntiles), dim3(256), 0, s, recs, meta, a.tile_sums, (uint32_t)g.k,
                      static_cast<uint4*>(zero_a), (uint32_t)(zero_a_bytes / 16), static_cast<uint4*>(zero_b),
                      (uint32_t)(zero_b_bytes / 16));
-  hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, a.tile_sums, ntiles, meta);
+  // (tile_sums has room for ntiles + 1 sums and QH_SCAN_SCRATCH words of scratch behind them)
+  uint32_t* sums = a.tile_sums + ntiles + 1;
+  const uint32_t nb = (ntiles + QS_BLOCK - 1) / QS_BLOCK;
+  if (nb) hipLaunchKernelGGL(k_scan_u32_sums, dim3(nb), dim3(256), 0, s, a.tile_sums, ntiles, sums, meta);
+  hipLaunchKernelGGL(k_scan_u32_top, dim3(1), dim3(1024), 0, s, a.tile_sums, ntiles, sums, nb);
+  if (nb) hipLaunchKernelGGL(k_scan_u32_apply, dim3(nb), dim3(256), 0, s, a.tile_sums, ntiles, sums, meta);
   hipLaunchKernelGGL(k_rec_segs_apply, dim3(ntiles), dim3(256), 0, s, recs, meta, a.tile_sums, (uint32_t)g.k, a.seg_desc);
 }
 

@@ -378,6 +378,8 @@ class ShardedBuilder:
         prev, self._inflight = self._inflight, None
         if prev is not None:
             self._insert(*prev)
+        if not self.pipelined:
+            self.h.flush()   # the pass over the table starts; whoever collects next waits for it
 
     def reset(self):
         self.flush()

@@ -156,6 +156,10 @@ class HashWithQuality:
     def reset(self):
         check(lib.qh_build_reset(self._h))
 
+    def flush(self):
+        """starts the pass over the table for what waits in the window buckets, without waiting for it"""
+        check(lib.qh_build_flush(self._h))
+
     def stats(self):
         st = _lib.QhBuildStats()
         check(lib.qh_build_get_stats(self._h, C.byref(st)))

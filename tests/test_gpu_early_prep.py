@@ -115,3 +115,70 @@ def test_malformed_chunk_prepared_early_is_rejected_whole(reads):
     m, v = sorted_pairs(*h.dump())
     assert h.stats()["instances"] == n and (m == om).all() and (v == ov).all()
     h.close()
+
+
+def test_builds_back_to_back_in_one_handle(reads):
+    """flush() starts the pass over the table and returns, reset() with that pass in flight only notes itself, and the
+    next build's first chunk is prepared beside the pass: three builds in a row, each collected by the one after it, the
+    last by done(). Every build's table is the oracle's for its own reads alone; a reset noted and then followed by a
+    read of the statistics shows an empty handle."""
+    chunks = device_chunks(reads, CHUNK_READS)
+    groups = [(0, 3), (3, 5), (5, 7)]
+    h = qa.HashWithQuality(SLOTS, 2 * K, BITS, min_qual=Q)
+    h.set_mode("partition")
+    h.set_defer(1 << 30)
+    first = 0
+    for gi, (a, b) in enumerate(groups):
+        if gi:
+            h.reset()                               # the pass of the build before is still running
+        for c in chunks[a:b]:
+            h.add_fastq_device(c.data_ptr(), c.numel())
+        if gi < len(groups) - 1:
+            h.flush()
+    st = h.done()
+    a, b = groups[-1]
+    lo, hi = sum(CHUNK_READS[:a]) * RB, sum(CHUNK_READS[:b]) * RB
+    db = po.OracleDB(2 * SLOTS, K, BITS)
+    n = db.add_fastq(reads[lo:hi].tobytes(), Q, threads=8)
+    om, ov = db.sorted_dump()
+    m, v = sorted_pairs(*h.dump())
+    assert st["instances"] == n and st["records"] == sum(CHUNK_READS[a:b]) and st["distinct"] == om.size
+    assert (m == om).all() and (v == ov).all()
+    assert st["early_preps"] == b - a               # the build's first chunk too: prepared beside the pass before it
+    # the middle build, looked at before the reset that follows it is applied
+    h.reset()
+    a, b = groups[1]
+    for c in chunks[a:b]:
+        h.add_fastq_device(c.data_ptr(), c.numel())
+    h.flush()
+    lo, hi = sum(CHUNK_READS[:a]) * RB, sum(CHUNK_READS[:b]) * RB
+    db = po.OracleDB(2 * SLOTS, K, BITS)
+    n = db.add_fastq(reads[lo:hi].tobytes(), Q, threads=8)
+    om, ov = db.sorted_dump()
+    m, v = sorted_pairs(*h.dump())
+    assert h.stats()["instances"] == n and (m == om).all() and (v == ov).all()
+    h.add_fastq_device(chunks[0].data_ptr(), chunks[0].numel())
+    h.reset()                                       # noted: the chunk is in flight
+    st = h.stats()                                  # collects it, then empties the handle
+    assert st["instances"] == 0 and st["distinct"] == 0 and st["records"] == 0
+    m, v = h.dump()
+    assert m.size == 0
+    h.close()
+
+
+def test_reset_swallows_the_format_error_of_the_chunk_in_flight(reads):
+    bad_np = reads[:20_000 * RB].copy()
+    bad_np[5 * RB + 3] = ord("\n")
+    bad = torch.from_numpy(bad_np).to("cuda:0")
+    good = device_chunks(reads, CHUNK_READS[:1])[0]
+    torch.cuda.synchronize()
+    h = qa.HashWithQuality(SLOTS, 2 * K, BITS, min_qual=Q)
+    h.set_mode("partition")
+    h.add_fastq_device(bad.data_ptr(), bad.numel())
+    h.reset()                                       # eager or noted: the rejected chunk goes with the rest
+    h.add_fastq_device(good.data_ptr(), good.numel())
+    st = h.done()
+    db = po.OracleDB(2 * SLOTS, K, BITS)
+    n = db.add_fastq(reads[:CHUNK_READS[0] * RB].tobytes(), Q, threads=8)
+    assert st["instances"] == n and st["records"] == CHUNK_READS[0]
+    h.close()
