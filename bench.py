@@ -132,7 +132,7 @@ def kernel_table(ktimes, st, steps, single, per_rank_step, shard_bits=0):
     wid = int(st["slots"]).bit_length() - 1 - 13
     b1 = wid if wid <= 8 else min((wid + 1) // 2, max(8, wid - 10))
     b2 = wid - b1
-    knames = ("segments(k_rec_segs_sum+k_scan_u32+k_rec_segs_apply)" if partitioned and single
+    knames = ("segments(k_rec_segs_sum+k_scan_u32_sums/top/apply+k_rec_segs_apply)" if partitioned and single
               else "k_build_direct" if single else "k_insert_items",
               # (the instantiations rocprofv3 lists for these geometries: k = 24, bin field in the low 32 bits, tile
               #  blocks and bucket limit; the shard handle of the pipeline checks the owner of what it receives)
