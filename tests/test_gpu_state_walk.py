@@ -1,6 +1,7 @@
 """Random walks over the builder's states: chunks of every size through every entry point (host text, device text back to
 back -- early preparation --, host-parsed text, mer lists on the host and on the device), strategies and deferral budgets
-switched on the way, collections, lookups on the live table, dumps and resets in between, on tables small enough to grow.
+switched on the way, collections, window passes started without waiting, lookups on the live table, dumps and resets
+(noted while work is in flight, applied at the next collection) in between, on tables small enough to grow.
 After every observation the table must equal the oracle's, which received the same inputs one by one
 (hash_with_quality::add is order independent, src/mer_database.hpp:94-113)."""
 import os
@@ -33,7 +34,7 @@ def reads_for(k, seed):
 WALKS = [(1, 24, 7, 1 << 22), (2, 31, 3, 1 << 20), (3, 17, 5, 1 << 23), (4, 24, 1, 1 << 18), (5, 31, 12, 1 << 22),
          (6, 12, 7, 1 << 22)]
 if os.environ.get("QH_WALK_EXTRA"):   # a soak run: QH_WALK_EXTRA=<n> adds n more walks over drawn geometries
-    _r = np.random.default_rng(2024)
+    _r = np.random.default_rng(int(os.environ.get("QH_WALK_SEED", "2024")))
     for _i in range(int(os.environ["QH_WALK_EXTRA"])):
         WALKS.append((100 + _i, int(_r.choice([9, 12, 15, 17, 20, 24, 27, 31])), int(_r.choice([1, 3, 7, 12, 20])),
                       1 << int(_r.integers(14, 25))))
@@ -68,7 +69,7 @@ def test_random_walk_matches_oracle(seed, k, bits, slots):
 
     for step in range(60):
         op = rng.choice(["text", "dev", "dev", "dev", "parsed", "mers", "devmers", "sync", "lookup", "dump", "reset",
-                         "defer", "mode"])
+                         "defer", "mode", "flush"])
         if op in ("text", "dev", "parsed"):
             n = int(rng.choice([1, 40, 3_000, 25_000, 60_000]))
             part = take(n)
@@ -117,6 +118,8 @@ def test_random_walk_matches_oracle(seed, k, bits, slots):
             keep.clear()
             db = po.OracleDB(1 << 24, k, bits)
             expect_inst = 0
+        elif op == "flush":
+            h.flush()                       # the pass over the table starts; whatever comes next collects it
         elif op == "defer":
             h.set_defer(int(rng.choice([0, 1 << 27, 1 << 30, -1])))
         elif op == "mode":
